@@ -1,0 +1,235 @@
+/* ptcore.h — C ABI of the MI355X render core for andreasots/pathtracer.
+ *
+ * The reference is one Rust crate with direct calls and no FFI; this header cuts the seam along
+ * the three call sites SURVEY.md §8(b) names and declares exactly what a `ptcore-sys` crate would
+ * bind (INTEGRATION.md shows that crate).  Plain C, opaque handles, caller-owned host arrays,
+ * every call returns an int status (0 = ok) and never throws or aborts across the boundary: the
+ * reference's panics on malformed input (scene.rs:43,53,121; bvh.rs:242-243) become error codes.
+ *
+ * Threading: one caller thread per pt_ctx (the reference's render job is a single rayon task
+ * tree, main.rs:58).  One pt_ctx drives ONE GPU (one process per GPU; multi-GPU callers shard
+ * the sample range across contexts/processes and sum the PT_RENDER_SUM buffers).
+ *
+ * All arithmetic is IEEE binary32, no FMA contraction, no fast-math — see DESIGN.md.
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------------- */
+enum {
+    PT_OK = 0,
+    PT_ERR_INVALID = 1,      /* bad argument / malformed scene (reference would panic)            */
+    PT_ERR_HIP = 2,          /* HIP runtime error, text in pt_last_error()                        */
+    PT_ERR_NOMEM = 3,
+    PT_ERR_UNSUPPORTED = 4,  /* valid in the reference, not built yet (see DESIGN.md scope)       */
+    PT_ERR_BVH_DEGENERATE = 5 /* BVH::build would hit assert!(!child_aabb.is_empty()) bvh.rs:242  */
+};
+
+#define PT_NO_TRIANGLE 0xFFFFFFFFu
+
+/* ---- plain-data mirrors of the reference's types ---------------------------------------- */
+
+/* AABB (bvh.rs:32-36). */
+typedef struct pt_aabb { float min[3]; float max[3]; } pt_aabb;
+
+/* enum BVHNode (bvh.rs:123-127) in `BVH.nodes` order (bvh.rs:341-343): preorder, root = [0],
+ * leaves are entries of their own and hold one index into the UNPERMUTED triangle array. */
+typedef struct pt_bvh_node {
+    uint32_t is_leaf;        /* 1: Leaf{shape_index}; 0: Node{..}                                 */
+    uint32_t shape_index;    /* Leaf                                                               */
+    uint32_t child_l_index;  /* Node                                                               */
+    uint32_t child_r_index;
+    pt_aabb  child_l_aabb;
+    pt_aabb  child_r_aabb;
+} pt_bvh_node;               /* 64 bytes */
+
+/* Arguments of Triangle::new (triangle.rs:42-49); the library recomputes n,d,n1,d1,n2,d2
+ * exactly as triangle.rs:50-60 does. */
+#define PT_TRI_HAS_UV      1u
+#define PT_TRI_HAS_NORMALS 2u
+typedef struct pt_triangle {
+    float a[3], b[3], c[3];
+    float uv[3][2];              /* valid iff flags & PT_TRI_HAS_UV                                */
+    float vertex_normals[3][3];  /* valid iff flags & PT_TRI_HAS_NORMALS                           */
+    uint32_t material_index;
+    uint32_t flags;
+} pt_triangle;                   /* 104 bytes */
+
+/* Texture<P> (material.rs:80-84).  Bilinear is never constructed by the reference loader
+ * (material.rs:215,228,246,249) and is not part of the ABI. */
+#define PT_TEX_FLAT    0u
+#define PT_TEX_NEAREST 1u
+typedef struct pt_texture {
+    uint32_t kind;
+    float    value[3];   /* Flat: linear-sRGB colour, or value[0] for a scalar (dissolve) texture */
+    uint32_t image;      /* Nearest: index into pt_scene_desc.images                               */
+} pt_texture;
+
+/* Image<P> (material.rs:12-16): row-major, (x, y) at texels[(x + y*width)*channels]. */
+typedef struct pt_image {
+    uint32_t width, height;
+    uint32_t channels;   /* 3 = Color<SRGB> (already linear), 1 = f32                              */
+    const float* texels;
+} pt_image;
+
+/* Material (material.rs:198-203). */
+#define PT_EMIT_NULL         0u
+#define PT_EMIT_ABSORBED_D65 1u
+typedef struct pt_material {
+    pt_texture diffuse;      /* Lambert.reflectance                                                */
+    uint32_t   emit_kind;
+    pt_texture absorption;   /* Emit::AbsorbedD65.absorption                                       */
+    float      base_dissolve;
+    pt_texture dissolve;     /* scalar                                                             */
+} pt_material;
+
+/* InitialisedSky (scene.rs:94-103) with the cooked HosekWilkieSkyModel fields
+ * (hosek_wilkie.rs:36-43; both emission_correction_factor arrays are all 1.0 and omitted). */
+#define PT_SKY_D65          0u
+#define PT_SKY_HOSEK_WILKIE 1u
+typedef struct pt_sky {
+    uint32_t kind;
+    float power;             /* D65                                                                */
+    float configs[11][9];
+    float radiances[11];
+    float turbidity;
+    float solar_radius;
+    float zenith[3];         /* camera space, normalised (scene.rs:115-116)                        */
+    float sun[3];            /* camera space, normalised (scene.rs:117-118)                        */
+} pt_sky;
+
+/* scene::Camera fields the render loop reads (scene.rs:134-140; camera.rs:11-17). */
+typedef struct pt_camera {
+    uint32_t width, height;
+    float sensor_width, focal_length;
+} pt_camera;
+
+/* Ray::new arguments (bvh.rs:380-386); direction is used as given, NOT normalised.
+ * 32 bytes so a lane fetches it as two aligned 16-byte loads. */
+typedef struct pt_ray {
+    float o[3]; float pad0;
+    float d[3]; float pad1;
+} pt_ray;
+
+/* Option<(&Triangle, Intersection)> (bvh.rs:358-363, triangle.rs:27-33): the triangle is returned
+ * by index; Intersection.normal is that triangle's `n` and is not repeated here. */
+typedef struct pt_hit {
+    uint32_t tri;            /* PT_NO_TRIANGLE = None                                              */
+    float t, u, v;           /* Intersection.distance (ray PARAMETER), u, v                        */
+} pt_hit;
+
+typedef struct pt_scene_desc {
+    const pt_triangle* triangles;  uint32_t n_triangles;
+    const pt_bvh_node* nodes;      uint32_t n_nodes;      /* 0 or 2*n_triangles-1                  */
+    const pt_material* materials;  uint32_t n_materials;  /* [0] = Material::default (scene.rs:204)*/
+    const pt_image*    images;     uint32_t n_images;
+    pt_sky sky;
+} pt_scene_desc;
+
+typedef struct pt_ctx pt_ctx;
+typedef struct pt_scene pt_scene;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+
+/* n must be 1: one context drives one GPU.  device_ids may be NULL (device 0). */
+int  pt_init(const int* device_ids, int n, pt_ctx** out);
+void pt_shutdown(pt_ctx* ctx);
+/* Text of the last error on this context (or of the last failed pt_init when ctx == NULL). */
+const char* pt_last_error(const pt_ctx* ctx);
+int  pt_abi_version(void);
+
+/* ---- host-side mirrors of what the Rust host keeps (bvh.rs / scene.rs / material.rs) ----- */
+
+/* BVH::build (bvh.rs:346-356 -> 134-248), bit-faithful: same split decisions, same preorder
+ * node vector.  nodes_out has room for 2*n-1 entries (n >= 1); *n_nodes_out receives the count
+ * (0 for n == 0).  Does not touch the GPU. */
+int pt_bvh_build(const pt_triangle* triangles, uint32_t n, pt_bvh_node* nodes_out,
+                 uint32_t* n_nodes_out);
+
+/* InitialisedSky::from_sky for Sky::HosekWilkie (scene.rs:109-127) + HosekWilkieSkyModel::new
+ * (hosek_wilkie.rs:46-72).  camera_transform is the 4x4 camera matrix, column-major as
+ * nalgebra's Matrix4::from([[f32;4];4]) (NULL = identity).  PT_ERR_INVALID when the solar
+ * elevation is not > 0 (scene.rs:121) or turbidity is outside [1, 10]. */
+int pt_sky_hosek_wilkie(float turbidity, float albedo, const float zenith[3], const float sun[3],
+                        const float* camera_transform, pt_sky* out);
+void pt_sky_d65(float power, pt_sky* out);
+/* Material::default() (material.rs:300-309). */
+void pt_material_default(pt_material* out);
+
+/* ---- seam 1: scene upload (replaces holding Scene{bvh,triangles,materials,sky}, scene.rs:273-281)
+ * Copies the caller's arrays, flattens nodes to the 64-byte device layout and triangles to the
+ * 48-byte intersect record + shading record, and owns the device memory until destroy. */
+int  pt_scene_create(pt_ctx* ctx, const pt_scene_desc* desc, pt_scene** out);
+void pt_scene_destroy(pt_ctx* ctx, pt_scene* scene);
+
+/* ---- seam 2: closest hit (replaces self.bvh.traverse(&ray, start, &self.triangles), scene.rs:333)
+ * start_tri may be NULL; an entry PT_NO_TRIANGLE means `start = None`.  Host pointers. */
+int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
+                     const uint32_t* start_tri, uint32_t n, pt_hit* out);
+/* Same with DEVICE pointers (rays/hits already resident in HBM); returns after the kernel has
+ * completed. */
+int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+                         const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out);
+
+/* Traversal flavour used by both calls above. */
+#define PT_TRAVERSE_FAST  0u  /* global-best pruning; same hit as the reference except on exact
+                                 equal-t ties                                          */
+#define PT_TRAVERSE_EXACT 1u  /* replays traverse_recursive's local pruning and tie rules
+                                 (bvh.rs:265-306) frame by frame                                   */
+int pt_set_traversal(pt_ctx* ctx, uint32_t mode);
+
+/* ---- seam 3: render (replaces the rayon closure main.rs:58-116) ---------------------------
+ * Renders sample indices [spp_begin, spp_begin+spp_count) of every pixel; sample s of pixel p
+ * draws from stream (seed, p, s) (pt_rng.h).  xyzw is W*H*4 floats, index 4*(x + y*W) + c
+ * (main.rs:102-107).
+ *   PT_RENDER_FINAL: xyz = sum * (1/spp_total), w = 1.0   (main.rs:49,100)
+ *   PT_RENDER_SUM:   xyz = raw sums over the range, w = spp_count  (shard partials; add, then scale) */
+#define PT_RENDER_FINAL 0u
+#define PT_RENDER_SUM   1u
+int pt_render(pt_ctx* ctx, const pt_scene* scene, const pt_camera* camera, uint32_t spp_begin,
+              uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* xyzw);
+int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera* camera, uint32_t spp_begin,
+                  uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode,
+                  float* d_xyzw);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+typedef struct pt_stats {
+    double   trace_ms;        /* HIP-event time of the traversal kernel(s) of the last call        */
+    uint64_t trace_rays;      /* rays those kernels traced                                         */
+    uint32_t trace_launches;
+    double   total_ms;        /* HIP-event time of the whole last call (device side)               */
+    uint64_t paths;           /* pt_render: camera paths started                                   */
+    uint64_t segments;        /* pt_render: path segments (traversals)                             */
+} pt_stats;
+int pt_get_stats(const pt_ctx* ctx, pt_stats* out);
+
+/* Scene facts the harness reports. */
+typedef struct pt_scene_info {
+    uint32_t n_triangles, n_internal_nodes, max_depth;
+    uint64_t device_bytes;
+} pt_scene_info;
+int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
+
+/* ---- harness helpers (no reference counterpart; synthetic workloads of SURVEY.md §8(d)) --- */
+
+/* "soup" triangle generator: centre ~ U(lo, hi), two edge vectors ~ U([-s, s]^3) with
+ * s = edge_scale (log_scale_hi > edge_scale: s log-uniform in [edge_scale, log_scale_hi]);
+ * material 1 + (i mod n_material_cycle).  Deterministic in (seed, i) via pt_rng.h. */
+int pt_gen_soup(uint64_t seed, uint32_t n, const float lo[3], const float hi[3], float edge_scale,
+                float log_scale_hi, uint32_t n_material_cycle, pt_triangle* out);
+/* Pixel-centre camera rays, Camera::generate_ray(x, y) (camera.rs:19-28), row-major. */
+int pt_gen_primary_rays(const pt_camera* camera, pt_ray* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTCORE_H */

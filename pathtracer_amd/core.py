@@ -1,0 +1,212 @@
+"""ctypes binding of libptcore.so — the Python-side stand-in for the `ptcore-sys` FFI crate.
+
+Everything that computes goes through the C ABI of include/ptcore.h; there is no Python or CPU
+fallback: if the HIP library is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptcore.so")
+_lib = None
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ptcore error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """The loaded libptcore.so (built in-tree by `make -C pathtracer_amd/csrc` / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: build it with `make -C pathtracer_amd/csrc` "
+            "(there is no CPU fallback for the render core)")
+    L = C.CDLL(_LIB_PATH)
+    vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
+    sig = {
+        "pt_abi_version": (i32, []),
+        "pt_init": (i32, [C.POINTER(i32), i32, C.POINTER(vp)]),
+        "pt_shutdown": (None, [vp]),
+        "pt_last_error": (C.c_char_p, [vp]),
+        "pt_bvh_build": (i32, [vp, u32, vp, C.POINTER(u32)]),
+        "pt_sky_hosek_wilkie": (i32, [f32, f32, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(abi.Sky)]),
+        "pt_sky_d65": (None, [f32, C.POINTER(abi.Sky)]),
+        "pt_material_default": (None, [vp]),
+        "pt_scene_create": (i32, [vp, C.POINTER(abi.SceneDesc), C.POINTER(vp)]),
+        "pt_scene_destroy": (None, [vp, vp]),
+        "pt_trace_closest": (i32, [vp, vp, vp, vp, u32, vp]),
+        "pt_trace_closest_dev": (i32, [vp, vp, vp, vp, u32, vp]),
+        "pt_set_traversal": (i32, [vp, u32]),
+        "pt_render": (i32, [vp, vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp]),
+        "pt_render_dev": (i32, [vp, vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp]),
+        "pt_get_stats": (i32, [vp, C.POINTER(abi.Stats)]),
+        "pt_scene_get_info": (i32, [vp, C.POINTER(abi.SceneInfo)]),
+        "pt_gen_soup": (i32, [u64, u32, C.POINTER(f32), C.POINTER(f32), f32, f32, u32, vp]),
+        "pt_gen_primary_rays": (i32, [C.POINTER(abi.Camera), vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "pt_abi_version", "pt_init", "pt_shutdown", "pt_last_error", "pt_bvh_build", "pt_sky_hosek_wilkie",
+    "pt_sky_d65", "pt_material_default", "pt_scene_create", "pt_scene_destroy", "pt_trace_closest",
+    "pt_trace_closest_dev", "pt_set_traversal", "pt_render", "pt_render_dev", "pt_get_stats",
+    "pt_scene_get_info", "pt_gen_soup", "pt_gen_primary_rays",
+]
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+# ---- host-side mirrors (no GPU needed) -------------------------------------------------------
+
+def bvh_build(triangles):
+    """BVH::build (bvh.rs:346-356): reference-order node vector for `triangles`."""
+    tris = np.ascontiguousarray(triangles, dtype=abi.TRIANGLE)
+    n = tris.size
+    nodes = np.zeros(max(2 * n - 1, 0), dtype=abi.BVH_NODE)
+    cnt = C.c_uint32(0)
+    rc = lib().pt_bvh_build(abi.ptr(tris) if n else None, n, abi.ptr(nodes) if n else None, C.byref(cnt))
+    if rc != abi.PT_OK:
+        raise PtError(rc, "pt_bvh_build failed")
+    return nodes[:cnt.value]
+
+
+def sky_d65(power):
+    s = abi.Sky()
+    lib().pt_sky_d65(float(power), C.byref(s))
+    return s
+
+
+def sky_hosek_wilkie(turbidity, albedo, zenith, sun, camera_transform=None):
+    s = abi.Sky()
+    m = None
+    if camera_transform is not None:
+        flat = np.asarray(camera_transform, dtype=np.float32).reshape(16)   # column-major
+        m = (C.c_float * 16)(*flat.tolist())
+    rc = lib().pt_sky_hosek_wilkie(float(turbidity), float(albedo), _f3(zenith), _f3(sun), m, C.byref(s))
+    if rc != abi.PT_OK:
+        raise PtError(rc, "pt_sky_hosek_wilkie: invalid sky (elevation <= 0 or turbidity outside [1,10])")
+    return s
+
+
+def gen_soup(seed, n, lo, hi, edge_scale, log_scale_hi=0.0, n_material_cycle=8):
+    out = np.zeros(n, dtype=abi.TRIANGLE)
+    rc = lib().pt_gen_soup(int(seed), int(n), _f3(lo), _f3(hi), float(edge_scale), float(log_scale_hi),
+                           int(n_material_cycle), abi.ptr(out))
+    if rc != abi.PT_OK:
+        raise PtError(rc, "pt_gen_soup failed")
+    return out
+
+
+def gen_primary_rays(width, height, sensor_width=36.0, focal_length=50.0):
+    cam = abi.Camera(width, height, sensor_width, focal_length)
+    out = np.zeros(width * height, dtype=abi.RAY)
+    rc = lib().pt_gen_primary_rays(C.byref(cam), abi.ptr(out))
+    if rc != abi.PT_OK:
+        raise PtError(rc, "pt_gen_primary_rays failed")
+    return out
+
+
+# ---- device side ------------------------------------------------------------------------------
+
+class Scene:
+    def __init__(self, ctx, handle, arrays):
+        self.ctx, self.handle, self.arrays = ctx, handle, arrays
+
+    def info(self):
+        i = abi.SceneInfo()
+        lib().pt_scene_get_info(self.handle, C.byref(i))
+        return i
+
+    def close(self):
+        if self.handle:
+            lib().pt_scene_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One pt_ctx = one GPU."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        ids = (C.c_int * 1)(int(device))
+        rc = lib().pt_init(ids, 1, C.byref(h))
+        if rc != abi.PT_OK:
+            raise PtError(rc, (lib().pt_last_error(None) or b"").decode())
+        self.handle = h
+
+    def _check(self, rc):
+        if rc != abi.PT_OK:
+            raise PtError(rc, (lib().pt_last_error(self.handle) or b"").decode())
+
+    def close(self):
+        if self.handle:
+            lib().pt_shutdown(self.handle)
+            self.handle = None
+
+    def scene(self, arrays):
+        d = arrays.desc()
+        h = C.c_void_p()
+        self._check(lib().pt_scene_create(self.handle, C.byref(d), C.byref(h)))
+        return Scene(self, h, arrays)
+
+    def set_traversal(self, mode):
+        self._check(lib().pt_set_traversal(self.handle, int(mode)))
+
+    def trace(self, scene, rays, start=None):
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY)
+        n = rays.size
+        out = np.zeros(n, dtype=abi.HIT)
+        st = None if start is None else np.ascontiguousarray(start, dtype=np.uint32)
+        self._check(lib().pt_trace_closest(self.handle, scene.handle, abi.ptr(rays), abi.ptr(st), n, abi.ptr(out)))
+        return out
+
+    def trace_dev(self, scene, d_rays, d_start, n, d_out):
+        self._check(lib().pt_trace_closest_dev(self.handle, scene.handle, C.c_void_p(d_rays),
+                                               C.c_void_p(d_start) if d_start else None, int(n), C.c_void_p(d_out)))
+
+    def render(self, scene, width, height, spp_begin, spp_count, spp_total, seed, mode=abi.PT_RENDER_FINAL,
+               sensor_width=36.0, focal_length=50.0):
+        cam = abi.Camera(width, height, sensor_width, focal_length)
+        out = np.zeros((height, width, 4), dtype=np.float32)
+        self._check(lib().pt_render(self.handle, scene.handle, C.byref(cam), spp_begin, spp_count, spp_total,
+                                    int(seed), int(mode), abi.ptr(out)))
+        return out
+
+    def render_dev(self, scene, width, height, spp_begin, spp_count, spp_total, seed, mode, d_out,
+                   sensor_width=36.0, focal_length=50.0):
+        cam = abi.Camera(width, height, sensor_width, focal_length)
+        self._check(lib().pt_render_dev(self.handle, scene.handle, C.byref(cam), spp_begin, spp_count, spp_total,
+                                        int(seed), int(mode), C.c_void_p(d_out)))
+
+    def stats(self):
+        s = abi.Stats()
+        lib().pt_get_stats(self.handle, C.byref(s))
+        return s
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

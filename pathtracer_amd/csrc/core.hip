@@ -1,0 +1,384 @@
+// core.hip — context, scene upload (flattening to the device layouts) and the closest-hit entry
+// points of the C ABI (include/ptcore.h).
+//
+// Scene upload replaces "hold Scene { bvh, triangles, materials, sky }" (scene.rs:185-191,
+// 273-281): the caller's reference-order node vector (enum BVHNode, bvh.rs:123-127) becomes an
+// internal-nodes-only array of 64-byte records, Triangle::new's precomputation
+// (triangle.rs:50-60) is redone here in the reference's operation order, and materials / sky /
+// spectral tables are copied to HBM once.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "device_types.h"
+#include "tables.h"
+#include "../../include/pt_math.h"
+
+static std::string g_init_error;
+static std::mutex g_init_mu;
+
+int ptc_fail(pt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    else { std::lock_guard<std::mutex> g(g_init_mu); g_init_error = msg; }
+    return code;
+}
+
+int ptc_hip(pt_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return PT_OK;
+    return ptc_fail(ctx, e == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP,
+                    std::string(what) + ": " + hipGetErrorString(e));
+}
+
+int ptc_reserve(pt_ctx* ctx, void** buf, size_t* have, size_t need, const char* what) {
+    if (*have >= need) return PT_OK;
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *have = 0; }
+    size_t want = need + need / 4;
+    hipError_t e = hipMalloc(buf, want);
+    if (e != hipSuccess) { want = need; e = hipMalloc(buf, want); }
+    if (e != hipSuccess) return ptc_hip(ctx, e, what);
+    *have = want;
+    return PT_OK;
+}
+
+extern "C" int pt_abi_version(void) { return PT_ABI_VERSION; }
+
+extern "C" const char* pt_last_error(const pt_ctx* ctx) {
+    if (ctx) return ctx->error.c_str();
+    std::lock_guard<std::mutex> g(g_init_mu);
+    return g_init_error.c_str();
+}
+
+extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
+    if (!out) return ptc_fail(nullptr, PT_ERR_INVALID, "pt_init: out is NULL");
+    *out = nullptr;
+    if (n != 1) return ptc_fail(nullptr, PT_ERR_INVALID, "pt_init: one context drives exactly one GPU (n must be 1)");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return ptc_fail(nullptr, PT_ERR_HIP, std::string("pt_init: no HIP device: ") + hipGetErrorString(e));
+    int dev = device_ids ? device_ids[0] : 0;
+    if (dev < 0 || dev >= count) return ptc_fail(nullptr, PT_ERR_INVALID, "pt_init: device id out of range");
+    auto ctx = std::make_unique<pt_ctx>();
+    ctx->device = dev;
+    if ((e = hipSetDevice(dev)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    ctx->n_cus = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+        return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    for (auto& ev : ctx->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    if ((e = hipHostMalloc((void**)&ctx->h_counters, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
+        return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    *out = ctx.release();
+    return PT_OK;
+}
+
+extern "C" void pt_shutdown(pt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->spill) (void)hipFree(ctx->spill);
+    if (ctx->work) (void)hipFree(ctx->work);
+    if (ctx->io) (void)hipFree(ctx->io);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int pt_set_traversal(pt_ctx* ctx, uint32_t mode) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (mode != PT_TRAVERSE_FAST && mode != PT_TRAVERSE_EXACT) return ptc_fail(ctx, PT_ERR_INVALID, "unknown traversal mode");
+    ctx->traversal = mode;
+    return PT_OK;
+}
+
+extern "C" int pt_get_stats(const pt_ctx* ctx, pt_stats* out) {
+    if (!ctx || !out) return PT_ERR_INVALID;
+    *out = ctx->stats;
+    return PT_OK;
+}
+
+extern "C" int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out) {
+    if (!scene || !out) return PT_ERR_INVALID;
+    *out = scene->info;
+    return PT_OK;
+}
+
+namespace {
+
+template <class T>
+int upload(pt_ctx* ctx, pt_scene* sc, const std::vector<T>& host, const T** dev, const char* what) {
+    *dev = nullptr;
+    size_t bytes = host.size() * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);          // keep pointers valid for empty arrays
+    void* p = nullptr;
+    int rc = ptc_hip(ctx, hipMalloc(&p, bytes), what);
+    if (rc != PT_OK) return rc;
+    sc->allocations.push_back(p);
+    sc->info.device_bytes += bytes;
+    if (!host.empty()) {
+        rc = ptc_hip(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice), what);
+        if (rc != PT_OK) return rc;
+    }
+    *dev = reinterpret_cast<const T*>(p);
+    return PT_OK;
+}
+
+inline float dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+inline void cross3(const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+int check_texture(pt_ctx* ctx, const pt_texture& t, const pt_scene_desc* d, uint32_t channels, const char* what) {
+    if (t.kind == PT_TEX_FLAT) return PT_OK;
+    if (t.kind != PT_TEX_NEAREST) return ptc_fail(ctx, PT_ERR_INVALID, std::string(what) + ": unknown texture kind");
+    if (t.image >= d->n_images) return ptc_fail(ctx, PT_ERR_INVALID, std::string(what) + ": image index out of range");
+    if (d->images[t.image].channels != channels)
+        return ptc_fail(ctx, PT_ERR_INVALID, std::string(what) + ": image has the wrong channel count");
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" void pt_scene_destroy(pt_ctx* ctx, pt_scene* scene) {
+    if (!scene) return;
+    if (ctx) { (void)hipSetDevice(ctx->device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
+    for (void* p : scene->allocations) (void)hipFree(p);
+    delete scene;
+}
+
+extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!d || !out) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: NULL argument");
+    *out = nullptr;
+    const uint32_t N = d->n_triangles;
+    if (N >= PTC_INDEX_MASK) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_scene_create: more than 2^30-2 triangles");
+    if (N && !d->triangles) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: triangles is NULL");
+    if (d->n_materials == 0 || !d->materials)
+        return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: materials[0] (Material::default) is required");
+    if (N == 0 ? d->n_nodes != 0 : d->n_nodes != 2 * N - 1)
+        return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: n_nodes must be 2*n_triangles-1 (BVH::build, one triangle per leaf)");
+    if (d->n_nodes && !d->nodes) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: nodes is NULL");
+    if (d->sky.kind != PT_SKY_D65 && d->sky.kind != PT_SKY_HOSEK_WILKIE)
+        return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: unknown sky kind");
+    if (d->sky.kind == PT_SKY_HOSEK_WILKIE && !(d->sky.turbidity >= 1.0f && d->sky.turbidity <= 10.0f))
+        return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: turbidity outside [1, 10] (hosek_wilkie.rs:348-353)");
+    PTC_HIP(ctx, hipSetDevice(ctx->device));
+
+    // ---- validate + flatten the node vector ------------------------------------------------------
+    // Every child index must point FORWARD (preorder) so that traversal terminates and never
+    // leaves the array; every triangle must be referenced by exactly one leaf.
+    const uint32_t n_nodes = d->n_nodes;
+    std::vector<uint32_t> internal_rank(n_nodes, 0u);
+    uint32_t n_internal = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const pt_bvh_node& nd = d->nodes[i];
+        if (nd.is_leaf) {
+            if (nd.shape_index >= N) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: leaf shape_index out of range");
+        } else {
+            if (nd.child_l_index <= i || nd.child_l_index >= n_nodes || nd.child_r_index <= i || nd.child_r_index >= n_nodes)
+                return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: child index is not a forward preorder index");
+            internal_rank[i] = n_internal++;
+        }
+    }
+    if (N && n_internal != N - 1) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: expected n_triangles-1 internal nodes");
+
+    std::vector<float4> nodes((size_t)n_internal * 4u);
+    uint32_t max_depth = 0;
+    {
+        // depth = internal nodes on the longest root-to-leaf path (bounds the traversal stack)
+        std::vector<uint32_t> depth(n_nodes, 0u);
+        if (n_nodes) depth[0] = d->nodes[0].is_leaf ? 0u : 1u;
+        std::vector<uint8_t> seen(N, 0);
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+            const pt_bvh_node& nd = d->nodes[i];
+            if (nd.is_leaf) {
+                if (seen[nd.shape_index]) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: triangle referenced by two leaves");
+                seen[nd.shape_index] = 1;
+                continue;
+            }
+            if (depth[i] == 0 && i != 0) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: node unreachable from the root");
+            if (depth[i] > max_depth) max_depth = depth[i];
+            auto ref_of = [&](uint32_t child) -> uint32_t {
+                const pt_bvh_node& c = d->nodes[child];
+                if (c.is_leaf) { depth[child] = depth[i]; return PTC_LEAF_BIT | c.shape_index; }
+                depth[child] = depth[i] + 1;
+                return internal_rank[child];
+            };
+            const uint32_t lref = ref_of(nd.child_l_index), rref = ref_of(nd.child_r_index);
+            float4* q = &nodes[(size_t)internal_rank[i] * 4u];
+            float lw, rw;
+            std::memcpy(&lw, &lref, 4); std::memcpy(&rw, &rref, 4);
+            q[0] = make_float4(nd.child_l_aabb.min[0], nd.child_l_aabb.min[1], nd.child_l_aabb.min[2], lw);
+            q[1] = make_float4(nd.child_l_aabb.max[0], nd.child_l_aabb.max[1], nd.child_l_aabb.max[2], rw);
+            q[2] = make_float4(nd.child_r_aabb.min[0], nd.child_r_aabb.min[1], nd.child_r_aabb.min[2], 0.0f);
+            q[3] = make_float4(nd.child_r_aabb.max[0], nd.child_r_aabb.max[1], nd.child_r_aabb.max[2], 0.0f);
+        }
+    }
+    if (max_depth > 4096) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_scene_create: BVH deeper than 4096 levels");
+
+    // ---- Triangle::new (triangle.rs:50-60) ---------------------------------------------------------
+    std::vector<float4> tris((size_t)N * 3u), shade((size_t)N * 5u);
+    for (uint32_t i = 0; i < N; ++i) {
+        const pt_triangle& t = d->triangles[i];
+        if (t.material_index >= d->n_materials)
+            return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: material_index out of range");
+        float ab[3], ac[3], n[3], n1[3], n2[3], tmp[3];
+        for (int k = 0; k < 3; ++k) { ab[k] = t.b[k] - t.a[k]; ac[k] = t.c[k] - t.a[k]; }
+        cross3(ab, ac, n);
+        const float dd = dot3(t.a, n);
+        const float nn = dot3(n, n);
+        cross3(ac, n, tmp);
+        for (int k = 0; k < 3; ++k) n1[k] = tmp[k] / nn;
+        const float d1 = -dot3(t.a, n1);
+        cross3(n, ab, tmp);
+        for (int k = 0; k < 3; ++k) n2[k] = tmp[k] / nn;
+        const float d2 = -dot3(t.a, n2);
+        tris[(size_t)i * 3 + 0] = make_float4(n[0], n[1], n[2], dd);
+        tris[(size_t)i * 3 + 1] = make_float4(n1[0], n1[1], n1[2], d1);
+        tris[(size_t)i * 3 + 2] = make_float4(n2[0], n2[1], n2[2], d2);
+        float mw, fw;
+        const uint32_t flags = t.flags & (PT_TRI_HAS_UV | PT_TRI_HAS_NORMALS);
+        std::memcpy(&mw, &t.material_index, 4); std::memcpy(&fw, &flags, 4);
+        float4* s = &shade[(size_t)i * 5];
+        s[0] = make_float4(mw, fw, t.uv[0][0], t.uv[0][1]);
+        s[1] = make_float4(t.uv[1][0], t.uv[1][1], t.uv[2][0], t.uv[2][1]);
+        s[2] = make_float4(t.vertex_normals[0][0], t.vertex_normals[0][1], t.vertex_normals[0][2], t.vertex_normals[1][0]);
+        s[3] = make_float4(t.vertex_normals[1][1], t.vertex_normals[1][2], t.vertex_normals[2][0], t.vertex_normals[2][1]);
+        s[4] = make_float4(t.vertex_normals[2][2], 0.0f, 0.0f, 0.0f);
+    }
+
+    // ---- materials, images ---------------------------------------------------------------------------
+    std::vector<DevImage> images(d->n_images);
+    std::vector<float> texels;
+    for (uint32_t i = 0; i < d->n_images; ++i) {
+        const pt_image& im = d->images[i];
+        if (!im.texels || im.width == 0 || im.height == 0 || (im.channels != 1 && im.channels != 3))
+            return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: bad image");
+        images[i] = DevImage{im.width, im.height, im.channels, (uint32_t)texels.size()};
+        texels.insert(texels.end(), im.texels, im.texels + (size_t)im.width * im.height * im.channels);
+    }
+    std::vector<DevMaterial> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const pt_material& m = d->materials[i];
+        int rc;
+        if ((rc = check_texture(ctx, m.diffuse, d, 3, "material.diffuse")) != PT_OK) return rc;
+        if ((rc = check_texture(ctx, m.dissolve, d, 1, "material.dissolve")) != PT_OK) return rc;
+        if (m.emit_kind != PT_EMIT_NULL && m.emit_kind != PT_EMIT_ABSORBED_D65)
+            return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: unknown emit kind");
+        if (m.emit_kind == PT_EMIT_ABSORBED_D65 && (rc = check_texture(ctx, m.absorption, d, 3, "material.absorption")) != PT_OK) return rc;
+        DevMaterial& o = mats[i];
+        for (int k = 0; k < 3; ++k) { o.diffuse[k] = m.diffuse.value[k]; o.absorb[k] = m.absorption.value[k]; }
+        o.diffuse_img = m.diffuse.kind == PT_TEX_NEAREST ? m.diffuse.image : 0xFFFFFFFFu;
+        o.absorb_img = (m.emit_kind == PT_EMIT_ABSORBED_D65 && m.absorption.kind == PT_TEX_NEAREST) ? m.absorption.image : 0xFFFFFFFFu;
+        o.base_dissolve = m.base_dissolve;
+        o.dissolve_value = m.dissolve.value[0];
+        o.dissolve_img = m.dissolve.kind == PT_TEX_NEAREST ? m.dissolve.image : 0xFFFFFFFFu;
+        o.emit_kind = m.emit_kind;
+    }
+
+    // ---- sky ------------------------------------------------------------------------------------------
+    auto sc = std::make_unique<pt_scene>();
+    DevSky& sky = sc->sky;
+    std::memset(&sky, 0, sizeof(sky));
+    sky.kind = d->sky.kind; sky.power = d->sky.power;
+    sky.turbidity = d->sky.turbidity; sky.solar_radius = d->sky.solar_radius;
+    std::memcpy(sky.zenith, d->sky.zenith, sizeof(sky.zenith));
+    std::memcpy(sky.sun, d->sky.sun, sizeof(sky.sun));
+    std::memcpy(sky.configs, d->sky.configs, sizeof(sky.configs));
+    std::memcpy(sky.radiances, d->sky.radiances, sizeof(sky.radiances));
+    std::vector<float> solar(11 * 2 * 45 * 4, 0.0f), limb(ptc_tab_hw_limb, ptc_tab_hw_limb + 66);
+    if (sky.kind == PT_SKY_HOSEK_WILKIE) {
+        uint32_t tl = pt_f2usize(sky.turbidity) - 1u;                         // hosek_wilkie.rs:355
+        if (tl > 8u) tl = 8u;
+        sky.turb_low = tl;
+        sky.turb_frac = sky.turbidity - (float)(tl + 1u);                     // :356
+        for (int wl = 0; wl < 11; ++wl)
+            for (int k = 0; k < 2; ++k)
+                std::memcpy(&solar[((size_t)wl * 2 + k) * 180], &ptc_tab_hw_solar[((size_t)wl * 10 + tl + k) * 180],
+                            180 * sizeof(float));
+    }
+    std::vector<float> refl(ptc_tab_srgb2refl, ptc_tab_srgb2refl + 471 * 3), d65(ptc_tab_d65, ptc_tab_d65 + 531);
+    std::vector<DevSky> skyv(1, sky);
+
+    // ---- upload ---------------------------------------------------------------------------------------
+    pt_scene* s = sc.get();
+    int rc;
+    const DevSky* d_sky = nullptr;
+    if ((rc = upload(ctx, s, nodes, &s->view.nodes, "nodes")) != PT_OK ||
+        (rc = upload(ctx, s, tris, &s->view.tris, "triangles")) != PT_OK ||
+        (rc = upload(ctx, s, shade, &s->view.shade, "shading records")) != PT_OK ||
+        (rc = upload(ctx, s, mats, &s->view.materials, "materials")) != PT_OK ||
+        (rc = upload(ctx, s, images, &s->view.images, "images")) != PT_OK ||
+        (rc = upload(ctx, s, texels, &s->view.texels, "texels")) != PT_OK ||
+        (rc = upload(ctx, s, refl, &s->view.refl_tab, "reflectance table")) != PT_OK ||
+        (rc = upload(ctx, s, d65, &s->view.d65_tab, "d65 table")) != PT_OK ||
+        (rc = upload(ctx, s, solar, &s->view.solar_tab, "solar table")) != PT_OK ||
+        (rc = upload(ctx, s, limb, &s->view.limb_tab, "limb table")) != PT_OK ||
+        (rc = upload(ctx, s, skyv, &d_sky, "sky")) != PT_OK) {
+        pt_scene_destroy(ctx, sc.release());
+        return rc;
+    }
+    s->d_sky = const_cast<DevSky*>(d_sky);
+    s->view.n_tris = N;
+    s->view.n_materials = d->n_materials;
+    s->view.max_depth = max_depth;
+    s->view.root_ref = (N == 1) ? (PTC_LEAF_BIT | d->nodes[0].shape_index) : 0u;
+    s->info.n_triangles = N;
+    s->info.n_internal_nodes = n_internal;
+    s->info.max_depth = max_depth;
+    *out = sc.release();
+    return PT_OK;
+}
+
+// ---- seam 2: closest hit ------------------------------------------------------------------------------
+
+extern "C" int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+                                    const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!scene || (n && (!d_rays || !d_out))) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest_dev: NULL argument");
+    PTC_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->stats = pt_stats{};
+    if (n == 0) return PT_OK;
+    PTC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    int rc = ptc_launch_trace(ctx, scene, d_rays, d_start_tri, nullptr, nullptr, n, d_out);
+    if (rc != PT_OK) return rc;
+    PTC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    PTC_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
+    float ms = 0.0f;
+    PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->stats.trace_ms = ms; ctx->stats.total_ms = ms;
+    ctx->stats.trace_rays = n; ctx->stats.trace_launches = 1;
+    return PT_OK;
+}
+
+extern "C" int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
+                                const uint32_t* start_tri, uint32_t n, pt_hit* out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!scene || (n && (!rays || !out))) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest: NULL argument");
+    if (n == 0) { ctx->stats = pt_stats{}; return PT_OK; }
+    PTC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t rb = (size_t)n * sizeof(pt_ray), sb = (size_t)n * sizeof(uint32_t), hb = (size_t)n * sizeof(pt_hit);
+    const size_t sb_pad = (sb + 255) & ~(size_t)255;
+    int rc = ptc_reserve(ctx, &ctx->io, &ctx->io_bytes, rb + sb_pad + hb, "ray staging");
+    if (rc != PT_OK) return rc;
+    char* base = (char*)ctx->io;
+    pt_ray* d_rays = (pt_ray*)base;
+    uint32_t* d_start = (uint32_t*)(base + rb);
+    pt_hit* d_out = (pt_hit*)(base + rb + sb_pad);
+    PTC_HIP(ctx, hipMemcpyAsync(d_rays, rays, rb, hipMemcpyHostToDevice, ctx->stream));
+    if (start_tri) PTC_HIP(ctx, hipMemcpyAsync(d_start, start_tri, sb, hipMemcpyHostToDevice, ctx->stream));
+    rc = pt_trace_closest_dev(ctx, scene, d_rays, start_tri ? d_start : nullptr, n, d_out);
+    if (rc != PT_OK) return rc;
+    PTC_HIP(ctx, hipMemcpyAsync(out, d_out, hb, hipMemcpyDeviceToHost, ctx->stream));
+    PTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}

@@ -1,0 +1,103 @@
+// device_types.h — HBM layouts of the render core and the context/scene objects behind the C ABI.
+#ifndef PTC_DEVICE_TYPES_H
+#define PTC_DEVICE_TYPES_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ptcore.h"
+
+// ---- child references -------------------------------------------------------------------------
+// bit 31: leaf (low bits = triangle index), else low bits = internal-node index.
+// bit 30 is reserved for the EXACT traversal's frame tag, so indices are < 2^30.
+#define PTC_LEAF_BIT  0x80000000u
+#define PTC_FRAME_BIT 0x40000000u
+#define PTC_INDEX_MASK 0x3FFFFFFFu
+#define PTC_NONE_ID   0x3FFFFFFFu      /* "no triangle" inside a tagged frame */
+
+// ---- BVH node: 64 B = 4 x float4, internal nodes only (N-1 of them), preorder among internals.
+// The boxes of both children live in the parent, as in enum BVHNode::Node (bvh.rs:126).
+//   q0 = { l.min.x, l.min.y, l.min.z, bits(left ref)  }
+//   q1 = { l.max.x, l.max.y, l.max.z, bits(right ref) }
+//   q2 = { r.min.x, r.min.y, r.min.z, 0 }
+//   q3 = { r.max.x, r.max.y, r.max.z, 0 }
+// ---- triangle intersect record: 48 B = 3 x float4 (triangle.rs:17-24)
+//   t0 = { n.xyz, d }   t1 = { n1.xyz, d1 }   t2 = { n2.xyz, d2 }
+// ---- triangle shading record: 80 B = 5 x float4; the common (no uv, no normals) case reads s0 only
+//   s0 = { bits(material), bits(flags), uv0.x, uv0.y }
+//   s1 = { uv1.x, uv1.y, uv2.x, uv2.y }
+//   s2 = { vn0.x, vn0.y, vn0.z, vn1.x }   s3 = { vn1.y, vn1.z, vn2.x, vn2.y }   s4 = { vn2.z, 0, 0, 0 }
+
+struct DevMaterial {        // 48 B
+    float diffuse[3];   uint32_t diffuse_img;      // 0xFFFFFFFF = Flat
+    float absorb[3];    uint32_t absorb_img;
+    float base_dissolve; float dissolve_value; uint32_t dissolve_img; uint32_t emit_kind;
+};
+
+struct DevImage { uint32_t width, height, channels, offset; };   // offset in floats into texel pool
+
+struct DevSky {
+    uint32_t kind; float power; float turbidity; float solar_radius;
+    float zenith[3]; float sun[3];
+    float configs[11][9];
+    float radiances[11];
+    uint32_t turb_low; float turb_frac;      // hosek_wilkie.rs:355-356, fixed per scene
+};
+
+struct DevSceneView {       // passed to kernels by value
+    const float4* nodes;
+    const float4* tris;
+    const float4* shade;
+    const DevMaterial* materials;
+    const DevImage* images;
+    const float* texels;
+    const float* refl_tab;      // [471][3]
+    const float* d65_tab;       // [531]
+    const float* solar_tab;     // [11][2][45][4]: the two turbidity rows the scene needs
+    const float* limb_tab;      // [11][6]
+    uint32_t root_ref;          // PTC_LEAF_BIT|0 for a 1-triangle scene
+    uint32_t n_tris;
+    uint32_t n_materials;
+    uint32_t max_depth;
+};
+
+struct pt_scene {
+    DevSceneView view{};
+    DevSky sky{};
+    DevSky* d_sky = nullptr;
+    std::vector<void*> allocations;
+    pt_scene_info info{};
+};
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t traversal = PT_TRAVERSE_FAST;
+    std::string error;
+    pt_stats stats{};
+    int n_cus = 0;
+    // reusable device workspaces (grown on demand, freed at shutdown)
+    void* spill = nullptr;      size_t spill_bytes = 0;
+    void* work = nullptr;       size_t work_bytes = 0;
+    void* io = nullptr;         size_t io_bytes = 0;
+    uint32_t* h_counters = nullptr;      // pinned
+};
+
+int ptc_fail(pt_ctx* ctx, int code, const std::string& msg);
+int ptc_hip(pt_ctx* ctx, hipError_t e, const char* what);
+int ptc_reserve(pt_ctx* ctx, void** buf, size_t* have, size_t need, const char* what);
+
+#define PTC_HIP(ctx, call)                                            \
+    do {                                                              \
+        int _rc = ptc_hip((ctx), (call), #call);                      \
+        if (_rc != PT_OK) return _rc;                                 \
+    } while (0)
+
+// launch helpers implemented in trace.hip / render.hip
+int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
+                     const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out);
+
+#endif

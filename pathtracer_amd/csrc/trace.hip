@@ -1,0 +1,326 @@
+// trace.hip — closest-hit BVH traversal + Havel–Herout ray/triangle test for gfx950.
+//
+// Replaces, on the device:
+//   Ray::new / Ray::intersects_aabb        bvh.rs:380-410
+//   BVHNode::traverse_recursive            bvh.rs:250-338   (BVH::traverse bvh.rs:358-369)
+//   Triangle::intersect                    triangle.rs:82-115
+//
+// One ray per lane, wave64.  The traversal stack is a per-lane SHORT stack in LDS laid out
+// [slot][lane] (8-byte entries, so a wave's push/pop is one conflict-free ds_write_b64 /
+// ds_read_b64); it is a ring: when a lane's ring is full the oldest entry spills to a per-lane
+// column in HBM ([depth][thread], coalesced) and comes back when the ring runs dry.  Nodes are
+// fetched as 4 x 16-byte loads and triangles as 3 x 16-byte loads per lane.
+//
+// Two flavours (pt_set_traversal):
+//  FAST   near-first DFS with ONE global best distance: a subtree is entered iff best > its entry
+//         distance, a leaf hit replaces the best iff t <= best (so among equal t the later
+//         visited wins, as bvh.rs:299-303).  Visits a subset of what the reference visits and
+//         returns the same minimum-t hit; only exact equal-t ties / hits exactly at a pruned
+//         box's entry distance can pick a different triangle.
+//  EXACT  replays the recursion frame by frame: the far child of a node is entered iff the NEAR
+//         SUBTREE's own result is farther than the far box (bvh.rs:285), no global pruning,
+//         result = first_distance < second_distance ? first : second (bvh.rs:299-303).  Frames
+//         live on the same LDS ring: an "A" frame {far ref, far tmin} waits for the near result,
+//         a "B" frame {first id | tag, first distance} waits for the far result.
+//
+// All float arithmetic is written in the reference's operation order and the file is compiled
+// with -ffp-contract=off: no FMA, IEEE division, minNum/maxNum for f32::min/max.
+
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "../../include/pt_math.h"
+
+#define PTC_BLOCK 256
+
+namespace {
+
+struct DRay { float ox, oy, oz, dx, dy, dz, ix, iy, iz; };
+
+__device__ __forceinline__ DRay make_ray(float4 o, float4 d) {
+    DRay r;
+    r.ox = o.x; r.oy = o.y; r.oz = o.z;
+    r.dx = d.x; r.dy = d.y; r.dz = d.z;
+    r.ix = 1.0f / d.x; r.iy = 1.0f / d.y; r.iz = 1.0f / d.z;      // bvh.rs:384
+    return r;
+}
+
+// Ray::intersects_aabb (bvh.rs:390-410); returns hit flag, entry distance in tmin
+__device__ __forceinline__ bool slab(const DRay& r, float bx0, float by0, float bz0, float bx1,
+                                     float by1, float bz1, float& tmin_out) {
+    float t1x = (bx0 - r.ox) * r.ix, t2x = (bx1 - r.ox) * r.ix;
+    float t1y = (by0 - r.oy) * r.iy, t2y = (by1 - r.oy) * r.iy;
+    float t1z = (bz0 - r.oz) * r.iz, t2z = (bz1 - r.oz) * r.iz;
+    float tmin = pt_fmin(t1x, t2x);
+    float tmax = pt_fmax(t1x, t2x);
+    tmin = pt_fmax(tmin, pt_fmin(t1y, t2y));
+    tmax = pt_fmin(tmax, pt_fmax(t1y, t2y));
+    tmin = pt_fmax(tmin, pt_fmin(t1z, t2z));
+    tmax = pt_fmin(tmax, pt_fmax(t1z, t2z));
+    tmin = pt_fmax(tmin, 0.0f);
+    tmin_out = tmin;
+    return tmax >= tmin;
+}
+
+// Triangle::intersect with max_distance = INFINITY (bvh.rs:332), branch-free until the verdict
+__device__ __forceinline__ bool tri_test(const DRay& r, float4 t0, float4 t1, float4 t2,
+                                         float& dist, float& uo, float& vo) {
+    float det = (r.dx * t0.x + r.dy * t0.y) + r.dz * t0.z;                   // triangle.rs:84
+    float t = t0.w - ((r.ox * t0.x + r.oy * t0.y) + r.oz * t0.z);            // :89
+    float m = pt_inf() * det - t;                                            // :91
+    float px = r.ox * det + r.dx * t;                                        // :95
+    float py = r.oy * det + r.dy * t;
+    float pz = r.oz * det + r.dz * t;
+    float u = ((px * t1.x + py * t1.y) + pz * t1.z) + det * t1.w;            // :96
+    float v = ((px * t2.x + py * t2.y) + pz * t2.z) + det * t2.w;            // :101
+    float du = det - u;
+    float duv = du - v;                                                      // (det - u) - v, :102
+    uint32_t bad = (pt_f2u(m) ^ pt_f2u(t)) | (pt_f2u(du) ^ pt_f2u(u)) | (pt_f2u(duv) ^ pt_f2u(v));
+    float inv = 1.0f / det;                                                  // :106
+    float d = t * inv;                                                       // :108
+    bool ok = (det != 0.0f) && ((bad >> 31) == 0u);
+    // relative_eq!(distance, 0.0): equal, or |distance| <= f32::EPSILON      :110
+    ok = ok && !(d == 0.0f || pt_fabs(d) <= 1.1920928955078125e-7f);
+    dist = d;
+    uo = u * inv;
+    vo = v * inv;
+    return ok;
+}
+
+// ---- per-lane ring stack: LDS window over an HBM column -----------------------------------------
+template <int S>
+struct LaneStack {
+    uint2* lds;          // &ring[0][tid]; slot stride = PTC_BLOCK
+    uint2* spill;        // &column[0][gtid]; depth stride = spill_stride
+    uint32_t spill_stride;
+    uint32_t sp;         // logical size
+    uint32_t base;       // entries [0, base) live in HBM, [base, sp) in LDS
+
+    __device__ __forceinline__ void reset() { sp = 0u; base = 0u; }
+    __device__ __forceinline__ void push(uint32_t a, uint32_t b) {
+        if (sp - base == (uint32_t)S) {
+            spill[(size_t)base * spill_stride] = lds[(base % S) * PTC_BLOCK];
+            base += 1u;
+        }
+        lds[(sp % S) * PTC_BLOCK] = make_uint2(a, b);
+        sp += 1u;
+    }
+    __device__ __forceinline__ uint2 pop() {     // caller checks sp > 0
+        sp -= 1u;
+        if (sp >= base) return lds[(sp % S) * PTC_BLOCK];
+        base = sp;
+        return spill[(size_t)sp * spill_stride];
+    }
+};
+
+__device__ __forceinline__ void load_node(const float4* nodes, uint32_t idx, float4& q0, float4& q1,
+                                          float4& q2, float4& q3) {
+    const float4* p = nodes + (size_t)idx * 4u;
+    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+}
+
+template <int S, bool QUEUED>
+__global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const float4* __restrict__ rays,
+                                                         const uint32_t* __restrict__ start,
+                                                         const uint32_t* __restrict__ queue,
+                                                         const uint32_t* __restrict__ count_ptr, uint32_t n,
+                                                         uint4* __restrict__ out, uint2* __restrict__ spill,
+                                                         uint32_t total_threads) {
+    __shared__ uint2 ring[S * PTC_BLOCK];
+    const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    if (count_ptr) n = *count_ptr;
+    LaneStack<S> st;
+    st.lds = &ring[threadIdx.x];
+    st.spill = spill + gtid;
+    st.spill_stride = total_threads;
+
+    for (uint32_t k = gtid; k < n; k += total_threads) {
+        const uint32_t i = QUEUED ? queue[k] : k;
+        const DRay r = make_ray(rays[2u * i], rays[2u * i + 1u]);
+        const uint32_t skip = start ? start[i] : PT_NO_TRIANGLE;
+        float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
+        uint32_t best_id = PT_NO_TRIANGLE;
+        st.reset();
+        uint32_t cur = sc.root_ref;
+        bool alive = sc.n_tris != 0u;
+        while (alive) {
+            if (cur & PTC_LEAF_BIT) {
+                const uint32_t tri = cur & PTC_INDEX_MASK;
+                if (tri != skip) {                                            // bvh.rs:329-330
+                    const float4* tp = sc.tris + (size_t)tri * 3u;
+                    float d, u, v;
+                    if (tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
+                        best_t = d; best_u = u; best_v = v; best_id = tri;
+                    }
+                }
+                // pop until something still worth entering
+                for (;;) {
+                    if (st.sp == 0u) { alive = false; break; }
+                    uint2 e = st.pop();
+                    if (best_t > __uint_as_float(e.y)) { cur = e.x; break; }
+                }
+            } else {
+                float4 q0, q1, q2, q3;
+                load_node(sc.nodes, cur, q0, q1, q2, q3);
+                float lt, rt;
+                bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);    // bvh.rs:260
+                bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);    // bvh.rs:261
+                lh = lh && (best_t > lt);
+                rh = rh && (best_t > rt);
+                const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
+                if (lh && rh) {
+                    const bool left_first = lt < rt;                          // bvh.rs:266
+                    st.push(left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
+                    cur = left_first ? lref : rref;
+                } else if (lh) {
+                    cur = lref;
+                } else if (rh) {
+                    cur = rref;
+                } else {
+                    for (;;) {
+                        if (st.sp == 0u) { alive = false; break; }
+                        uint2 e = st.pop();
+                        if (best_t > __uint_as_float(e.y)) { cur = e.x; break; }
+                    }
+                }
+            }
+        }
+        out[i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
+                            __float_as_uint(best_u), __float_as_uint(best_v));
+    }
+}
+
+// EXACT: frame-by-frame replay of traverse_recursive.
+template <int S, bool QUEUED>
+__global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, const float4* __restrict__ rays,
+                                                          const uint32_t* __restrict__ start,
+                                                          const uint32_t* __restrict__ queue,
+                                                          const uint32_t* __restrict__ count_ptr, uint32_t n,
+                                                          uint4* __restrict__ out, uint2* __restrict__ spill,
+                                                          uint32_t total_threads) {
+    __shared__ uint2 ring[S * PTC_BLOCK];
+    const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    if (count_ptr) n = *count_ptr;
+    LaneStack<S> st;
+    st.lds = &ring[threadIdx.x];
+    st.spill = spill + gtid;
+    st.spill_stride = total_threads;
+
+    for (uint32_t k = gtid; k < n; k += total_threads) {
+        const uint32_t i = QUEUED ? queue[k] : k;
+        const DRay r = make_ray(rays[2u * i], rays[2u * i + 1u]);
+        const uint32_t skip = start ? start[i] : PT_NO_TRIANGLE;
+        // value being returned up the (virtual) call stack: None = {NONE_ID, +inf}
+        uint32_t ret_id = PTC_NONE_ID;
+        float ret_t = pt_inf();
+        st.reset();
+        uint32_t cur = sc.root_ref;
+        bool descending = sc.n_tris != 0u;
+        bool alive = descending;
+        while (alive) {
+            if (descending) {
+                if (cur & PTC_LEAF_BIT) {                                     // bvh.rs:327-336
+                    const uint32_t tri = cur & PTC_INDEX_MASK;
+                    ret_id = PTC_NONE_ID; ret_t = pt_inf();
+                    if (tri != skip) {
+                        const float4* tp = sc.tris + (size_t)tri * 3u;
+                        float d, u, v;
+                        if (tri_test(r, tp[0], tp[1], tp[2], d, u, v)) { ret_id = tri; ret_t = d; }
+                    }
+                    descending = false;
+                } else {
+                    float4 q0, q1, q2, q3;
+                    load_node(sc.nodes, cur, q0, q1, q2, q3);
+                    float lt, rt;
+                    const bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);
+                    const bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);
+                    const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
+                    if (lh && rh) {                                           // bvh.rs:264-270
+                        const bool left_first = lt < rt;
+                        // A frame: far ref (tag bit clear) + far entry distance
+                        st.push(left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
+                        cur = left_first ? lref : rref;
+                    } else if (lh) {
+                        cur = lref;                                           // bvh.rs:308-315
+                    } else if (rh) {
+                        cur = rref;                                           // bvh.rs:316-323
+                    } else {
+                        ret_id = PTC_NONE_ID; ret_t = pt_inf();               // bvh.rs:324
+                        descending = false;
+                    }
+                }
+            } else {
+                if (st.sp == 0u) { alive = false; break; }
+                const uint2 e = st.pop();
+                const bool is_b = ((e.x & PTC_FRAME_BIT) != 0u) && ((e.x & PTC_LEAF_BIT) == 0u);
+                if (!is_b) {
+                    // near subtree returned `ret`; bvh.rs:280-285
+                    const float first_distance = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
+                    if (first_distance > __uint_as_float(e.y)) {
+                        st.push(PTC_FRAME_BIT | ret_id, __float_as_uint(ret_t));   // B frame keeps `first`
+                        cur = e.x;
+                        descending = true;
+                    }
+                    // else: return first_intersection unchanged (bvh.rs:304-306)
+                } else {
+                    // far subtree returned `ret`; bvh.rs:294-303
+                    const uint32_t f_id = e.x & PTC_INDEX_MASK;
+                    const float f_t = __uint_as_float(e.y);
+                    const float fd = (f_id != PTC_NONE_ID) ? f_t : pt_inf();
+                    const float sd = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
+                    if (fd < sd) { ret_id = f_id; ret_t = f_t; }
+                }
+            }
+        }
+        uint4 o = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
+        if (ret_id != PTC_NONE_ID) {
+            // u, v of the winner: the same arithmetic on the same inputs gives the same bits
+            const float4* tp = sc.tris + (size_t)ret_id * 3u;
+            float d, u, v;
+            tri_test(r, tp[0], tp[1], tp[2], d, u, v);
+            o = make_uint4(ret_id, __float_as_uint(d), __float_as_uint(u), __float_as_uint(v));
+        }
+        out[i] = o;
+    }
+}
+
+}  // namespace
+
+// Leaf refs carry PTC_LEAF_BIT with PTC_FRAME_BIT clear (indices < 2^30), internal refs have both
+// clear, so an A frame never looks like a B frame.
+
+int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
+                     const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out) {
+    if (n == 0) return PT_OK;
+    const DevSceneView& v = scene->view;
+    // resident grid: 8 blocks of 256 per CU at most; fewer when the batch is small
+    uint32_t max_blocks = (uint32_t)ctx->n_cus * 8u;
+    uint32_t blocks = (n + PTC_BLOCK - 1) / PTC_BLOCK;
+    if (blocks > max_blocks) blocks = max_blocks;
+    const uint32_t total_threads = blocks * PTC_BLOCK;
+    // HBM spill columns: depth entries per thread (EXACT needs one frame per tree level too)
+    const size_t depth = (size_t)v.max_depth + 2u;
+    int rc = ptc_reserve(ctx, &ctx->spill, &ctx->spill_bytes, depth * total_threads * sizeof(uint2), "spill");
+    if (rc != PT_OK) return rc;
+    constexpr int S = 8;
+    const float4* rays = reinterpret_cast<const float4*>(d_rays);
+    uint4* out = reinterpret_cast<uint4*>(d_out);
+    uint2* spill = reinterpret_cast<uint2*>(ctx->spill);
+    dim3 grid(blocks), block(PTC_BLOCK);
+    if (ctx->traversal == PT_TRAVERSE_EXACT) {
+        if (d_queue)
+            hipLaunchKernelGGL((k_trace_exact<S, true>), grid, block, 0, ctx->stream, v, rays, d_start, d_queue,
+                               d_count, n, out, spill, total_threads);
+        else
+            hipLaunchKernelGGL((k_trace_exact<S, false>), grid, block, 0, ctx->stream, v, rays, d_start, d_queue,
+                               d_count, n, out, spill, total_threads);
+    } else {
+        if (d_queue)
+            hipLaunchKernelGGL((k_trace_fast<S, true>), grid, block, 0, ctx->stream, v, rays, d_start, d_queue,
+                               d_count, n, out, spill, total_threads);
+        else
+            hipLaunchKernelGGL((k_trace_fast<S, false>), grid, block, 0, ctx->stream, v, rays, d_start, d_queue,
+                               d_count, n, out, spill, total_threads);
+    }
+    return ptc_hip(ctx, hipGetLastError(), "trace kernel launch");
+}

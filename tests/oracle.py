@@ -1,0 +1,189 @@
+"""ctypes wrapper of the CPU oracle (oracle/libptoracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pathtracer_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+FN_EXP, FN_LOG, FN_ACOS, FN_SIN, FN_CBRT, FN_POW1P5, FN_PPF, FN_ASIN = range(8)
+
+
+def _build_if_needed(name):
+    path = os.path.join(ORACLE_DIR, name)
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, name])
+    return path
+
+
+class OracleScene:
+    def __init__(self, o, handle, arrays):
+        self.o, self.handle, self.arrays = o, handle, arrays
+
+    def nodes(self):
+        n = self.o.L.pto_scene_n_nodes(self.handle)
+        out = np.zeros(n, dtype=abi.BVH_NODE)
+        if n:
+            self.o.L.pto_scene_get_nodes(self.handle, abi.ptr(out))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.o.L.pto_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Oracle:
+    def __init__(self, libm=False):
+        self.L = L = C.CDLL(_build_if_needed("libptoracle_libm.so" if libm else "libptoracle.so"))
+        vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
+        pf = C.POINTER(f32)
+        sig = {
+            "pto_triangle_intersect": (i32, [pf, pf, pf, pf, pf, f32, pf]),
+            "pto_triangle_precompute": (None, [vp, pf]),
+            "pto_ray_aabb": (i32, [pf, pf, pf, pf, pf]),
+            "pto_camera_ray": (None, [u32, u32, f32, f32, f32, f32, pf]),
+            "pto_from_wavelength": (None, [f32, pf]),
+            "pto_reflectance_at_one": (f32, [pf, f32]),
+            "pto_d65": (f32, [f32]),
+            "pto_srgb_to_xyz": (None, [pf, pf]),
+            "pto_sky_hosek_wilkie": (i32, [f32, f32, pf, pf, pf, C.POINTER(abi.Sky)]),
+            "pto_scene_create": (i32, [C.POINTER(abi.SceneDesc), C.POINTER(vp)]),
+            "pto_scene_destroy": (None, [vp]),
+            "pto_scene_n_nodes": (u32, [vp]),
+            "pto_scene_get_nodes": (None, [vp, vp]),
+            "pto_trace": (None, [vp, vp, vp, u64, vp, C.POINTER(u64), i32]),
+            "pto_trace_brute": (None, [vp, vp, vp, u64, vp, i32]),
+            "pto_trace_globalbest_stats": (None, [vp, vp, u64, vp, C.POINTER(u64)]),
+            "pto_evaluate_sky": (None, [vp, pf, pf, pf]),
+            "pto_render": (None, [vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp, C.POINTER(u64), i32]),
+            "pto_math": (f32, [i32, f32]),
+            "pto_philox": (None, [C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+            "pto_rng_draw": (None, [u64, u32, u32, i32, f32, f32, u32, pf, C.POINTER(u32)]),
+            "pto_uses_libm": (i32, []),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        self.nthreads = min(os.cpu_count() or 1, 16)
+
+    @staticmethod
+    def _f(v):
+        return (C.c_float * len(v))(*[float(x) for x in v])
+
+    # --- unit probes ---
+    def triangle_intersect(self, a, b, c, o, d, max_distance=float("inf")):
+        out = (C.c_float * 6)()
+        ok = self.L.pto_triangle_intersect(self._f(a), self._f(b), self._f(c), self._f(o), self._f(d),
+                                           max_distance, out)
+        return (np.array(out[:], dtype=np.float32) if ok else None)
+
+    def triangle_precompute(self, tri):
+        out = (C.c_float * 12)()
+        t = np.ascontiguousarray(tri, dtype=abi.TRIANGLE)
+        self.L.pto_triangle_precompute(abi.ptr(t), out)
+        return np.array(out[:], dtype=np.float32)
+
+    def ray_aabb(self, o, d, bmin, bmax):
+        t = C.c_float()
+        ok = self.L.pto_ray_aabb(self._f(o), self._f(d), self._f(bmin), self._f(bmax), C.byref(t))
+        return np.float32(t.value) if ok else None
+
+    def camera_ray(self, w, h, sensor, focal, x, y):
+        out = (C.c_float * 3)()
+        self.L.pto_camera_ray(w, h, sensor, focal, x, y, out)
+        return np.array(out[:], dtype=np.float32)
+
+    def from_wavelength(self, wl):
+        out = (C.c_float * 3)()
+        self.L.pto_from_wavelength(wl, out)
+        return np.array(out[:], dtype=np.float32)
+
+    def reflectance(self, rgb, wl):
+        return np.float32(self.L.pto_reflectance_at_one(self._f(rgb), wl))
+
+    def d65(self, wl):
+        return np.float32(self.L.pto_d65(wl))
+
+    def srgb_to_xyz(self, rgb):
+        out = (C.c_float * 3)()
+        self.L.pto_srgb_to_xyz(self._f(rgb), out)
+        return np.array(out[:], dtype=np.float32)
+
+    def sky_hosek_wilkie(self, turbidity, albedo, zenith, sun, camera_transform=None):
+        s = abi.Sky()
+        m = None
+        if camera_transform is not None:
+            m = self._f(np.asarray(camera_transform, dtype=np.float32).reshape(16))
+        rc = self.L.pto_sky_hosek_wilkie(turbidity, albedo, self._f(zenith), self._f(sun), m, C.byref(s))
+        return rc, s
+
+    def math(self, fn, xs):
+        xs = np.asarray(xs, dtype=np.float32)
+        return np.array([self.L.pto_math(fn, float(x)) for x in xs.ravel()], dtype=np.float32).reshape(xs.shape)
+
+    def philox(self, ctr, key):
+        out = (C.c_uint32 * 4)()
+        self.L.pto_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        return list(out)
+
+    def rng_draw(self, seed, pixel, sample, kind, n, lo=0.0, hi=1.0):
+        out = np.zeros(n * (3 if kind == 4 else 1), dtype=np.float32)
+        idx = C.c_uint32()
+        self.L.pto_rng_draw(seed, pixel, sample, kind, lo, hi, n, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(idx))
+        return (out.view(np.uint32) if kind == 0 else out), idx.value
+
+    # --- scene level ---
+    def scene(self, arrays):
+        d = arrays.desc()
+        h = C.c_void_p()
+        rc = self.L.pto_scene_create(C.byref(d), C.byref(h))
+        if rc != abi.PT_OK:
+            raise RuntimeError(f"oracle scene_create failed: {rc}")
+        return OracleScene(self, h, arrays)
+
+    def trace(self, scene, rays, start=None, count=False):
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY)
+        out = np.zeros(rays.size, dtype=abi.HIT)
+        st = None if start is None else np.ascontiguousarray(start, dtype=np.uint32)
+        cnt = (C.c_uint64 * 2)(0, 0)
+        self.L.pto_trace(scene.handle, abi.ptr(rays), abi.ptr(st), rays.size, abi.ptr(out), cnt, self.nthreads)
+        return (out, (cnt[0], cnt[1])) if count else out
+
+    def trace_brute(self, scene, rays, start=None):
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY)
+        out = np.zeros(rays.size, dtype=abi.HIT)
+        st = None if start is None else np.ascontiguousarray(start, dtype=np.uint32)
+        self.L.pto_trace_brute(scene.handle, abi.ptr(rays), abi.ptr(st), rays.size, abi.ptr(out), self.nthreads)
+        return out
+
+    def trace_globalbest_stats(self, scene, rays):
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY)
+        out = np.zeros(rays.size, dtype=abi.HIT)
+        cnt = (C.c_uint64 * 4)(0, 0, 0, 0)
+        self.L.pto_trace_globalbest_stats(scene.handle, abi.ptr(rays), rays.size, abi.ptr(out), cnt)
+        return out, list(cnt)
+
+    def evaluate_sky(self, scene, d, wl):
+        out = (C.c_float * 8)()
+        self.L.pto_evaluate_sky(scene.handle, self._f(d), self._f(wl), out)
+        return np.array(out[:], dtype=np.float32)
+
+    def render(self, scene, width, height, spp_begin, spp_count, spp_total, seed, mode=abi.PT_RENDER_FINAL,
+               sensor_width=36.0, focal_length=50.0, count=False, nthreads=None):
+        cam = abi.Camera(width, height, sensor_width, focal_length)
+        out = np.zeros((height, width, 4), dtype=np.float32)
+        cnt = (C.c_uint64 * 4)(0, 0, 0, 0)
+        self.L.pto_render(scene.handle, C.byref(cam), spp_begin, spp_count, spp_total, seed, mode, abi.ptr(out), cnt,
+                          nthreads or self.nthreads)
+        return (out, list(cnt)) if count else out
