@@ -1,11 +1,367 @@
-// render.hip — placeholder until the wavefront integrator lands (next commit).
-#include "device_types.h"
+// render.hip — wavefront spectral path tracer: generate -> [extend -> shade -> compact]* -> accumulate.
+//
+// Replaces the rayon sample loop and Scene::radiance:
+//   main.rs:64-109     per pixel, per sample: jitter, camera ray, hero wavelengths, radiance, XYZ
+//   scene.rs:307-374   the path loop (<= 16 scatter vertices, <= 1024 iterations, Russian roulette
+//                      from the 3rd vertex, dissolve pass-through, sky on miss, back-to-front fold)
+//   material.rs:255-297  Material::sample (dissolve test, normal, Lambert sphere offset, emission)
+//
+// One PASS renders `spp_pass` consecutive sample indices of every pixel at once: path id
+// p = s_local * (W*H) + pixel.  Per-path state lives in HBM as structure-of-arrays indexed by the
+// path id; QUEUES hold the ids of live paths.  Each iteration the traversal kernel (trace.hip)
+// extends every queued ray, then the shade kernel consumes the hits, pushes one {weight, emit}
+// vertex per scatter into the path's vertex column and appends surviving paths to the next queue
+// with a wave-level ballot/prefix compaction (one atomic per wave).
+//
+// The vertex column stores the sub-path exactly as the reference's ArrayVec<Bounce, 16> does, so
+// the accumulate kernel can fold it back to front, L = L*w + e (scene.rs:371-373), in the
+// reference's order — with 288 GB of HBM the 1 KiB per path is cheap, and a bounce costs one 64-B
+// write per path instead of a read-modify-write of throughput and radiance.  Each pixel's samples
+// are added in sample order by the one lane that owns the pixel, so the image is a deterministic
+// function of (scene, camera, seed, sample range) and equals the CPU checker's bit for bit
+// wherever the two agree on every hit.
+#include <hip/hip_runtime.h>
 
-extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene*, const pt_camera*, uint32_t, uint32_t, uint32_t,
-                             uint64_t, uint32_t, float*) {
-    return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_dev: integrator not built yet");
+#include <algorithm>
+
+#include "device_types.h"
+#include "shading.h"
+#include "../../include/pt_rng.h"
+
+#define PTC_BLOCK 256
+#define PTC_MAX_VERTS 16        /* ArrayVec<_, 16>, scene.rs:324 */
+#define PTC_MAX_ITERS 1024u     /* scene.rs:328 */
+
+namespace {
+
+struct PassState {
+    float4*   rays;       // [P][2]  pt_ray layout (origin, direction), consumed by trace.hip
+    uint4*    hits;       // [P]
+    uint32_t* start;      // [P]  triangle the ray leaves (Option<&Triangle> start)
+    uint32_t* rng_index;  // [P]  draws consumed so far by the path's stream
+    uint32_t* len_iter;   // [P]  len | iterations << 8
+    float*    hero;       // [P]
+    float*    verts;      // [16][2][8][P]: vertex k, {weight, emit}, wavelength i, path p
+    uint32_t* queue[2];   // [P] each
+    uint32_t* counts;     // [2] live-path counters of the two queues
+    uint32_t  P;          // paths in this pass
+    uint32_t  npix;
+};
+
+__device__ __forceinline__ size_t vert_index(uint32_t k, uint32_t which, uint32_t i, uint32_t p, uint32_t P) {
+    return ((size_t)((k * 2u + which) * PTC_NW + i)) * P + p;
 }
-extern "C" int pt_render(pt_ctx* ctx, const pt_scene*, const pt_camera*, uint32_t, uint32_t, uint32_t,
-                         uint64_t, uint32_t, float*) {
-    return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_render: integrator not built yet");
+
+// ---- generate: main.rs:76-89 -----------------------------------------------------------------------
+__global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera cam, uint64_t seed,
+                                                       uint32_t sample_base) {
+    const uint32_t p = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    if (p >= st.P) return;
+    const uint32_t pixel = p % st.npix;
+    const uint32_t sample = sample_base + p / st.npix;
+    const uint32_t px = pixel % cam.width, py = pixel / cam.width;
+    pt_rng rng;
+    pt_rng_init(&rng, seed, pixel, sample, 0u);
+    const float x = (float)px + pt_rng_normal(&rng) * 0.5f;                     // main.rs:77
+    const float y = (float)py + pt_rng_normal(&rng) * 0.5f;                     // main.rs:78
+    // Camera::new + generate_ray (camera.rs:11-28)
+    const float w = (float)cam.width, h = (float)cam.height;
+    const float sx = 1.0f / (w + 1.0f), sy = 1.0f / (h + 1.0f);
+    const float sensor1 = cam.sensor_width * h / w;
+    const float dx = ((x + 0.5f) * sx - 0.5f) * cam.sensor_width;
+    const float dy = -((y + 0.5f) * sy - 0.5f) * sensor1;
+    const float dz = -cam.focal_length;
+    const float hero = pt_rng_uniform(&rng, 0.0f, pt_uniform_scale(0.0f, (830.0f - 360.0f) / (float)PTC_NW));  // main.rs:83-84
+    st.rays[2u * p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    st.rays[2u * p + 1u] = make_float4(dx, dy, dz, 0.0f);
+    st.start[p] = PT_NO_TRIANGLE;
+    st.rng_index[p] = rng.index;
+    st.len_iter[p] = 0u;
+    st.hero[p] = hero;
+    st.queue[0][p] = p;
+}
+
+// ---- shade: one iteration of the loop body scene.rs:333-368 ------------------------------------------
+__global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, const DevSky* __restrict__ sky, PassState st,
+                                                    uint32_t cur, uint32_t count, uint64_t seed,
+                                                    uint32_t sample_base) {
+    const uint32_t k = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    bool cont = false;
+    uint32_t p = 0u;
+    if (k < count) {
+        p = st.queue[cur][k];
+        const uint4 hit = st.hits[p];
+        const float4 ro = st.rays[2u * p], rd = st.rays[2u * p + 1u];
+        uint32_t li = st.len_iter[p];
+        uint32_t len = li & 0xFFu, iter = li >> 8;
+        float wl[PTC_NW];
+        ptc::wavelengths(st.hero[p], wl);
+        const uint32_t P = st.P;
+
+        if (hit.x == PT_NO_TRIANGLE) {
+            // miss: push {0, sky} and stop (scene.rs:362-367)
+            float e[PTC_NW];
+            ptc::evaluate_sky(sc, sky, rd.x, rd.y, rd.z, wl, e);
+#pragma unroll
+            for (int i = 0; i < PTC_NW; ++i) {
+                st.verts[vert_index(len, 0u, i, p, P)] = 0.0f;
+                st.verts[vert_index(len, 1u, i, p, P)] = e[i];
+            }
+            len += 1u;
+        } else {
+            const uint32_t tri = hit.x;
+            const float dist = __uint_as_float(hit.y), hu = __uint_as_float(hit.z), hv = __uint_as_float(hit.w);
+            const float4* srec = sc.shade + (size_t)tri * 5u;
+            const float4 s0 = srec[0];
+            const uint32_t mat_id = __float_as_uint(s0.x), flags = __float_as_uint(s0.y);
+            const DevMaterial m = sc.materials[mat_id];
+            float u = hu, v = hv;
+            if (flags & PT_TRI_HAS_UV) {                                        // material.rs:266-270
+                const float4 s1 = srec[1];
+                const float w0 = 1.0f - hu - hv;
+                u = w0 * s0.z + hu * s1.x + hv * s1.z;
+                v = w0 * s0.w + hu * s1.y + hv * s1.w;
+            }
+            pt_rng rng;
+            pt_rng_init(&rng, seed, p % st.npix, sample_base + p / st.npix, st.rng_index[p]);
+            float dis = m.dissolve_value;
+            if (m.dissolve_img != 0xFFFFFFFFu) {
+                float g, b; const float flat[3] = {dis, dis, dis};
+                ptc::texture_rgb(sc, m.dissolve_img, flat, u, v, dis, g, b);
+            }
+            const float px = ro.x + rd.x * dist, py = ro.y + rd.y * dist, pz = ro.z + rd.z * dist;   // material.rs:292
+            if (pt_rng_f32(&rng) >= m.base_dissolve * dis) {                    // material.rs:275
+                // dissolved: pass straight through (scene.rs:357-361)
+                st.rays[2u * p] = make_float4(px, py, pz, 0.0f);
+                st.start[p] = tri;
+                cont = true;
+            } else {
+                float nx, ny, nz;
+                if (flags & PT_TRI_HAS_NORMALS) {                               // material.rs:279-282
+                    const float4 s2 = srec[2], s3 = srec[3], s4 = srec[4];
+                    const float w0 = 1.0f - hu - hv;
+                    nx = w0 * s2.x + hu * s2.w + hv * s3.z;
+                    ny = w0 * s2.y + hu * s3.x + hv * s3.w;
+                    nz = w0 * s2.z + hu * s3.y + hv * s4.x;
+                } else {
+                    const float4 t0 = sc.tris[(size_t)tri * 3u];                // Intersection.normal = tri.n
+                    nx = t0.x; ny = t0.y; nz = t0.z;
+                }
+                if (!(ptc::dot3(nx, ny, nz, rd.x, rd.y, rd.z) < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }   // :288
+                const float nlen = pt_sqrt(ptc::dot3(nx, ny, nz, nx, ny, nz));  // :290 normalize()
+                nx = nx / nlen; ny = ny / nlen; nz = nz / nlen;
+                float sph[3];
+                pt_rng_unit_sphere(&rng, sph);                                  // material.rs:168
+                const float ndx = nx + sph[0], ndy = ny + sph[1], ndz = nz + sph[2];
+                float cr, cg, cb;
+                ptc::texture_rgb(sc, m.diffuse_img, m.diffuse, u, v, cr, cg, cb);
+                float weight[PTC_NW], emit[PTC_NW];
+#pragma unroll
+                for (int i = 0; i < PTC_NW; ++i) weight[i] = ptc::reflectance_at_one(sc.refl_tab, cr, cg, cb, wl[i]);
+                if (m.emit_kind == PT_EMIT_ABSORBED_D65) {                      // material.rs:183-185
+                    float ar, ag, ab;
+                    ptc::texture_rgb(sc, m.absorb_img, m.absorb, u, v, ar, ag, ab);
+#pragma unroll
+                    for (int i = 0; i < PTC_NW; ++i)
+                        emit[i] = ptc::d65_one(sc.d65_tab, wl[i]) * ptc::reflectance_at_one(sc.refl_tab, ar, ag, ab, wl[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PTC_NW; ++i) emit[i] = 0.0f;
+                }
+                bool survive = true;
+                if (len > 1u) {                                                 // scene.rs:342-353
+                    float mx = weight[0];
+#pragma unroll
+                    for (int i = 1; i < PTC_NW; ++i) mx = (weight[i] > mx) ? weight[i] : mx;
+                    if (pt_rng_f32(&rng) < mx) {
+#pragma unroll
+                        for (int i = 0; i < PTC_NW; ++i) weight[i] = weight[i] / mx;
+                    } else {
+                        survive = false;
+#pragma unroll
+                        for (int i = 0; i < PTC_NW; ++i) weight[i] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PTC_NW; ++i) {
+                    st.verts[vert_index(len, 0u, i, p, P)] = weight[i];
+                    st.verts[vert_index(len, 1u, i, p, P)] = emit[i];
+                }
+                len += 1u;
+                if (survive) {                                                  // scene.rs:354-356
+                    st.rays[2u * p] = make_float4(px, py, pz, 0.0f);
+                    st.rays[2u * p + 1u] = make_float4(ndx, ndy, ndz, 0.0f);
+                    st.start[p] = tri;
+                    cont = true;
+                }
+            }
+            st.rng_index[p] = rng.index;
+        }
+        iter += 1u;
+        // loop header: `for _ in 0..1024` and the capacity check scene.rs:328-331
+        cont = cont && (len < PTC_MAX_VERTS) && (iter < PTC_MAX_ITERS);
+        st.len_iter[p] = len | (iter << 8);
+    }
+    // wave-level compaction into the next queue: ballot -> popcount prefix -> one atomic per wave
+    const unsigned long long mask = __ballot(cont);
+    if (mask != 0ull) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0u;
+        if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) base = atomicAdd(&st.counts[cur ^ 1u], (uint32_t)__popcll(mask));
+        base = __shfl(base, __ffsll((long long)mask) - 1);
+        if (cont) {
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            st.queue[cur ^ 1u][base + rank] = p;
+        }
+    }
+}
+
+// ---- accumulate: fold + CMF + pixel sum (scene.rs:371-373, main.rs:93-97) -----------------------------
+__global__ __launch_bounds__(PTC_BLOCK) void k_accumulate(PassState st, uint32_t spp_pass, float4* __restrict__ acc) {
+    const uint32_t pixel = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    if (pixel >= st.npix) return;
+    float4 a = acc[pixel];
+    const uint32_t P = st.P;
+    for (uint32_t s = 0; s < spp_pass; ++s) {
+        const uint32_t p = s * st.npix + pixel;
+        const uint32_t len = st.len_iter[p] & 0xFFu;
+        float L[PTC_NW];
+#pragma unroll
+        for (int i = 0; i < PTC_NW; ++i) L[i] = 0.0f;
+        for (uint32_t k = len; k-- > 0u;) {
+#pragma unroll
+            for (int i = 0; i < PTC_NW; ++i)
+                L[i] = L[i] * st.verts[vert_index(k, 0u, i, p, P)] + st.verts[vert_index(k, 1u, i, p, P)];
+        }
+        float wl[PTC_NW];
+        ptc::wavelengths(st.hero[p], wl);
+#pragma unroll
+        for (int i = 0; i < PTC_NW; ++i) {
+            float X, Y, Z;
+            ptc::from_wavelength(wl[i], X, Y, Z);
+            a.x += X * L[i] * (1.0f / (float)PTC_NW);
+            a.y += Y * L[i] * (1.0f / (float)PTC_NW);
+            a.z += Z * L[i] * (1.0f / (float)PTC_NW);
+        }
+    }
+    acc[pixel] = a;
+}
+
+// main.rs:100-107 (FINAL) or raw sums (SUM)
+__global__ __launch_bounds__(PTC_BLOCK) void k_output(const float4* __restrict__ acc, float4* __restrict__ out,
+                                                     uint32_t npix, uint32_t mode, float inv_total, float count) {
+    const uint32_t pixel = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    if (pixel >= npix) return;
+    const float4 a = acc[pixel];
+    if (mode == PT_RENDER_FINAL) out[pixel] = make_float4(a.x * inv_total, a.y * inv_total, a.z * inv_total, 1.0f);
+    else out[pixel] = make_float4(a.x, a.y, a.z, count);
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
+                             uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* d_xyzw) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!scene || !cam || !d_xyzw) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: NULL argument");
+    if (cam->width == 0 || cam->height == 0) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: empty image");
+    if (mode != PT_RENDER_FINAL && mode != PT_RENDER_SUM) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: unknown mode");
+    if (mode == PT_RENDER_FINAL && spp_total == 0) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: spp_total is 0");
+    const uint64_t npix64 = (uint64_t)cam->width * cam->height;
+    if (npix64 > (1ull << 28)) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_render_dev: image larger than 2^28 pixels");
+    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: sample range overflows");
+    const uint32_t npix = (uint32_t)npix64;
+    PTC_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->stats = pt_stats{};
+
+    // paths per pass: about 4M in flight (1 KiB of vertex column each), whole samples only
+    uint32_t spp_pass = (uint32_t)std::max<uint64_t>(1, (4ull << 20) / npix);
+    if (spp_pass > spp_count) spp_pass = spp_count ? spp_count : 1u;
+    const uint32_t Pmax = spp_pass * npix;
+
+    // ---- carve the workspace ---------------------------------------------------------------------
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_acc = carve((size_t)npix * sizeof(float4));
+    const size_t o_rays = carve((size_t)Pmax * 2 * sizeof(float4));
+    const size_t o_hits = carve((size_t)Pmax * sizeof(uint4));
+    const size_t o_start = carve((size_t)Pmax * 4), o_rng = carve((size_t)Pmax * 4), o_li = carve((size_t)Pmax * 4);
+    const size_t o_hero = carve((size_t)Pmax * 4);
+    const size_t o_q0 = carve((size_t)Pmax * 4), o_q1 = carve((size_t)Pmax * 4);
+    const size_t o_cnt = carve(256);
+    const size_t o_verts = carve((size_t)Pmax * PTC_MAX_VERTS * 2 * PTC_NW * sizeof(float));
+    int rc = ptc_reserve(ctx, &ctx->work, &ctx->work_bytes, off, "render workspace");
+    if (rc != PT_OK) return rc;
+    char* base = (char*)ctx->work;
+    float4* acc = (float4*)(base + o_acc);
+    PassState st{};
+    st.rays = (float4*)(base + o_rays); st.hits = (uint4*)(base + o_hits);
+    st.start = (uint32_t*)(base + o_start); st.rng_index = (uint32_t*)(base + o_rng);
+    st.len_iter = (uint32_t*)(base + o_li); st.hero = (float*)(base + o_hero);
+    st.queue[0] = (uint32_t*)(base + o_q0); st.queue[1] = (uint32_t*)(base + o_q1);
+    st.counts = (uint32_t*)(base + o_cnt); st.verts = (float*)(base + o_verts);
+    st.npix = npix;
+
+    hipStream_t s = ctx->stream;
+    PTC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+    PTC_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * sizeof(float4), s));
+    const uint32_t pix_blocks = (npix + PTC_BLOCK - 1) / PTC_BLOCK;
+    double trace_ms = 0.0;
+
+    for (uint32_t done = 0; done < spp_count; done += spp_pass) {
+        const uint32_t this_spp = std::min(spp_pass, spp_count - done);
+        const uint32_t P = this_spp * npix;
+        const uint32_t sample_base = spp_begin + done;
+        st.P = P;
+        hipLaunchKernelGGL(k_generate, dim3((P + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, st, *cam, seed, sample_base);
+        ctx->stats.paths += P;
+        uint32_t live = P, cur = 0;
+        while (live != 0) {
+            PTC_HIP(ctx, hipMemsetAsync(&st.counts[cur ^ 1u], 0, sizeof(uint32_t), s));
+            PTC_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+            rc = ptc_launch_trace(ctx, scene, (const pt_ray*)st.rays, st.start, st.queue[cur], nullptr, live, (pt_hit*)st.hits);
+            if (rc != PT_OK) return rc;
+            PTC_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+            hipLaunchKernelGGL(k_shade, dim3((live + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, scene->view,
+                               scene->d_sky, st, cur, live, seed, sample_base);
+            PTC_HIP(ctx, hipMemcpyAsync(ctx->h_counters, &st.counts[cur ^ 1u], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            PTC_HIP(ctx, hipStreamSynchronize(s));
+            float ms = 0.0f;
+            PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            trace_ms += ms;
+            ctx->stats.trace_rays += live;
+            ctx->stats.trace_launches += 1;
+            ctx->stats.segments += live;
+            live = ctx->h_counters[0];
+            cur ^= 1u;
+        }
+        hipLaunchKernelGGL(k_accumulate, dim3(pix_blocks), dim3(PTC_BLOCK), 0, s, st, this_spp, acc);
+    }
+    const float inv_total = (mode == PT_RENDER_FINAL) ? 1.0f / (float)spp_total : 0.0f;
+    hipLaunchKernelGGL(k_output, dim3(pix_blocks), dim3(PTC_BLOCK), 0, s, acc, (float4*)d_xyzw, npix, mode, inv_total,
+                       (float)spp_count);
+    PTC_HIP(ctx, hipGetLastError());
+    PTC_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+    PTC_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
+    float total = 0.0f;
+    PTC_HIP(ctx, hipEventElapsedTime(&total, ctx->ev[2], ctx->ev[3]));
+    ctx->stats.total_ms = total;
+    ctx->stats.trace_ms = trace_ms;
+    return PT_OK;
+}
+
+extern "C" int pt_render(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
+                         uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* xyzw) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!scene || !cam || !xyzw) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render: NULL argument");
+    PTC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)cam->width * cam->height * 4 * sizeof(float);
+    if (bytes == 0) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render: empty image");
+    int rc = ptc_reserve(ctx, &ctx->io, &ctx->io_bytes, bytes, "image staging");
+    if (rc != PT_OK) return rc;
+    rc = pt_render_dev(ctx, scene, cam, spp_begin, spp_count, spp_total, seed, mode, (float*)ctx->io);
+    if (rc != PT_OK) return rc;
+    PTC_HIP(ctx, hipMemcpy(xyzw, ctx->io, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
 }

@@ -1,0 +1,198 @@
+// shading.h — device-side spectral shading: what the reference evaluates per path vertex.
+//
+//   Color<SRGB>::reflectance_at_one     color.rs:41-54
+//   Color<XYZ>::from_wavelength         color.rs:72-93
+//   D65::sample_one                     material.rs:132-141
+//   Texture::sample (Flat / Nearest)    material.rs:90-100,124
+//   HosekWilkieSkyModel::radiance_one / solar_radiance_one and helpers   hosek_wilkie.rs:74-131,306-383
+//   Scene::evaluate_sky                 scene.rs:284-305
+//
+// Every expression keeps the reference's association order (nalgebra dot = (x*x' + y*y') + z*z',
+// lerp = a*(1-t) + b*t; a*b*c = (a*b)*c) and the file is built with -ffp-contract=off, so the CPU
+// checker, which runs the same operations, produces the same bits.  Transcendentals come from
+// include/pt_math.h on both sides.
+#ifndef PTC_SHADING_H
+#define PTC_SHADING_H
+
+#include "device_types.h"
+#include "../../include/pt_math.h"
+
+#define PTC_NW 8                       /* COLOR_SAMPLES, main.rs:26 */
+
+namespace ptc {
+
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// wavelengths of one sample from its hero offset (main.rs:82-89)
+__device__ __forceinline__ void wavelengths(float hero, float wl[PTC_NW]) {
+    const float width = 830.0f - 360.0f;
+#pragma unroll
+    for (int i = 0; i < PTC_NW; ++i) wl[i] = 360.0f + (hero + width * ((float)i / (float)PTC_NW));
+}
+
+__device__ __forceinline__ float reflectance_at_one(const float* __restrict__ tab, float r, float g, float b,
+                                                    float wl) {
+    const float offset = wl - 360.0f;
+    const float index = pt_floor(offset);
+    const float alpha = offset - index;
+    const uint32_t i = pt_f2usize(index);
+    float b0x = 0.0f, b0y = 0.0f, b0z = 0.0f, b1x = 0.0f, b1y = 0.0f, b1z = 0.0f;
+    if (i < 471u) { b0x = tab[3u * i]; b0y = tab[3u * i + 1u]; b0z = tab[3u * i + 2u]; }
+    if (i < 470u) { b1x = tab[3u * i + 3u]; b1y = tab[3u * i + 4u]; b1z = tab[3u * i + 5u]; }
+    const float w0 = 1.0f - alpha;
+    const float bx = b0x * w0 + b1x * alpha;
+    const float by = b0y * w0 + b1y * alpha;
+    const float bz = b0z * w0 + b1z * alpha;
+    return dot3(r, g, b, bx, by, bz);
+}
+
+__device__ __forceinline__ float d65_one(const float* __restrict__ tab, float wl) {
+    const float offset = pt_floor(wl) - 300.0f;
+    const float index = pt_floor(offset);
+    const float alpha = offset - index;
+    const uint32_t i = pt_f2usize(index);
+    const float t0 = (i < 531u) ? tab[i] : 0.0f;
+    const float t1 = (i < 530u) ? tab[i + 1u] : 0.0f;
+    return t0 * (1.0f - alpha) + t1 * alpha;
+}
+
+__device__ __forceinline__ float cmf_lobe(float wl, float weight, float mean, float s1, float s2) {
+    const float t = (wl - mean) * (wl < mean ? s1 : s2);
+    return weight * pt_expf(-0.5f * (t * t));
+}
+__device__ __forceinline__ void from_wavelength(float wl, float& X, float& Y, float& Z) {
+    X = cmf_lobe(wl, 0.362f, 442.0f, 0.0624f, 0.0374f) + cmf_lobe(wl, 1.056f, 599.8f, 0.0264f, 0.0323f)
+        + cmf_lobe(wl, -0.065f, 501.1f, 0.0490f, 0.0382f);
+    Y = cmf_lobe(wl, 0.821f, 568.8f, 0.0213f, 0.0247f) + cmf_lobe(wl, 0.286f, 530.9f, 0.0613f, 0.0322f);
+    Z = cmf_lobe(wl, 1.217f, 437.0f, 0.0845f, 0.0278f) + cmf_lobe(wl, 0.681f, 459.0f, 0.0385f, 0.0725f);
+}
+
+__device__ __forceinline__ float rem_euclid1(float x) {
+    const float r = x - pt_trunc(x);           // x % 1.0, exact
+    return (r < 0.0f) ? r + 1.0f : r;
+}
+
+// Texture::sample.  img == 0xFFFFFFFF: Flat(value)
+__device__ __forceinline__ void texture_rgb(const DevSceneView& sc, uint32_t img, const float flat[3], float u,
+                                            float v, float& r, float& g, float& b) {
+    if (img == 0xFFFFFFFFu) { r = flat[0]; g = flat[1]; b = flat[2]; return; }
+    const DevImage im = sc.images[img];
+    uint32_t x = pt_f2usize(pt_floor(rem_euclid1(u) * (float)im.width));
+    uint32_t y = pt_f2usize(pt_floor((1.0f - rem_euclid1(v)) * (float)im.height));
+    x %= im.width; y %= im.height;
+    const float* p = sc.texels + im.offset + ((size_t)x + (size_t)y * im.width) * im.channels;
+    if (im.channels == 3u) { r = p[0]; g = p[1]; b = p[2]; }
+    else { r = g = b = p[0]; }
+}
+
+// ---- Hosek-Wilkie ---------------------------------------------------------------------------------
+__device__ __forceinline__ float sq(float x) { return x * x; }
+__device__ __forceinline__ float pow3(float x) { return x * (x * x); }
+__device__ __forceinline__ float pow4(float x) { const float s = x * x; return s * s; }
+__device__ __forceinline__ float pow5(float x) { const float s = x * x; return x * (s * s); }
+
+__device__ __forceinline__ float hw_radiance_internal(const float* __restrict__ c, float cos_theta, float gamma,
+                                                      float cos_gamma) {          // hosek_wilkie.rs:306-325
+    const float exp_m = pt_expf(c[4] * gamma);
+    const float ray_m = cos_gamma * cos_gamma;
+    const float mie_m = (1.0f + cos_gamma * cos_gamma) / pt_pow1p5(1.0f + c[8] * c[8] - 2.0f * c[8] * cos_gamma);
+    const float zenith = pt_sqrt(cos_theta);
+    return (1.0f + c[0] * pt_expf(c[1] / (cos_theta + 0.01f)))
+           * (c[2] + c[3] * exp_m + c[5] * ray_m + c[6] * mie_m + c[7] * zenith);
+}
+
+__device__ __forceinline__ float hw_radiance_one(const DevSky* __restrict__ sky, float cos_theta, float gamma,
+                                                 float cos_gamma, float wl) {     // hosek_wilkie.rs:74-102
+    const float band = (wl - 320.0f) / 40.0f;
+    const uint32_t low = pt_f2usize(band);
+    if (low >= 11u) return 0.0f;
+    const float interp = pt_fract_rem(band);
+    const float val_low = hw_radiance_internal(sky->configs[low], cos_theta, gamma, cos_gamma) * sky->radiances[low];
+    if (interp < 1e-6f) return val_low;
+    float result = (1.0f - interp) * val_low;
+    if (low + 1u < 11u)
+        result += interp * hw_radiance_internal(sky->configs[low + 1u], cos_theta, gamma, cos_gamma)
+                  * sky->radiances[low + 1u];
+    return result;
+}
+
+// sr_internal (hosek_wilkie.rs:327-345); `row` selects turb_low (0) or turb_low+1 (1)
+__device__ __forceinline__ float hw_sr(const float* __restrict__ solar, uint32_t row, uint32_t wl, float elevation) {
+    uint32_t pos = pt_f2usize(pt_cbrtf(2.0f * elevation / 3.14159265358979323846f) * 45.0f);
+    if (pos > 44u) pos = 44u;
+    const float break_x = pow3((float)pos / 45.0f) * 1.57079632679489661923f;
+    const float x = elevation - break_x;
+    const float* c = solar + ((wl * 2u + row) * 45u + pos) * 4u;
+    float res = 0.0f, x_exp = 1.0f;
+    res += x_exp * c[3]; x_exp *= x;
+    res += x_exp * c[2]; x_exp *= x;
+    res += x_exp * c[1]; x_exp *= x;
+    res += x_exp * c[0];
+    return res;
+}
+
+__device__ __forceinline__ float hw_solar_direct(const DevSceneView& sc, const DevSky* __restrict__ sky, float wl,
+                                                 float elevation, float gamma) {  // hosek_wilkie.rs:347-383
+    const float turb_frac = sky->turb_frac;
+    uint32_t wl_low = pt_f2usize((wl - 320.0f) / 40.0f);
+    if (wl_low > 9u) wl_low = 9u;
+    const float wl_frac = (wl - 320.0f - (float)wl_low * 40.0f) / 40.0f;
+    const float* S = sc.solar_tab;
+    const float direct =
+        (1.0f - turb_frac) * ((1.0f - wl_frac) * hw_sr(S, 0u, wl_low, elevation) + wl_frac * hw_sr(S, 0u, wl_low + 1u, elevation))
+        + turb_frac * ((1.0f - wl_frac) * hw_sr(S, 1u, wl_low, elevation) + wl_frac * hw_sr(S, 1u, wl_low + 1u, elevation));
+    float ld[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        ld[i] = (1.0f - wl_frac) * sc.limb_tab[wl_low * 6u + i] + wl_frac * sc.limb_tab[(wl_low + 1u) * 6u + i];
+    const float srs = pt_sinf(sky->solar_radius);
+    const float ar2 = 1.0f / (srs * srs);
+    const float sg = pt_sinf(gamma);
+    const float scos = pt_sqrt(pt_fmax(1.0f - ar2 * sg * sg, 0.0f));
+    const float dark = ld[0] + ld[1] * scos + ld[2] * sq(scos) + ld[3] * pow3(scos) + ld[4] * pow4(scos) + ld[5] * pow5(scos);
+    return direct * dark;
+}
+
+// Scene::evaluate_sky (scene.rs:284-305); d is the UN-normalised ray direction
+__device__ __forceinline__ void evaluate_sky(const DevSceneView& sc, const DevSky* __restrict__ sky, float dx,
+                                             float dy, float dz, const float wl[PTC_NW], float out[PTC_NW]) {
+    if (sky->kind == PT_SKY_D65) {
+        const float power = sky->power;
+        if (power == 0.0f) {
+#pragma unroll
+            for (int i = 0; i < PTC_NW; ++i) out[i] = 0.0f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < PTC_NW; ++i) out[i] = d65_one(sc.d65_tab, wl[i]) * power;
+        }
+        return;
+    }
+    const float cos_theta = dot3(dx, dy, dz, sky->zenith[0], sky->zenith[1], sky->zenith[2]);
+    if (cos_theta > 0.0f) {
+        const float theta = pt_acosf(pt_fmin(cos_theta, 1.0f));
+        const float cos_gamma = dot3(dx, dy, dz, sky->sun[0], sky->sun[1], sky->sun[2]);
+        const float gamma = pt_acosf(pt_fmax(pt_fmin(cos_gamma, 1.0f), -1.0f));
+        if (gamma < sky->solar_radius) {
+            for (int i = 0; i < PTC_NW; ++i) {                                    // hosek_wilkie.rs:114-131
+                const float w = wl[i];
+                float v = 0.0f;
+                if (!(w < 320.0f || w > 720.0f)) {
+                    const float direct = hw_solar_direct(sc, sky, w, 1.57079632679489661923f - theta, gamma);
+                    const float inscattered = hw_radiance_one(sky, cos_theta, gamma, cos_gamma, w);
+                    v = direct + inscattered;
+                }
+                out[i] = v;
+            }
+        } else {
+            for (int i = 0; i < PTC_NW; ++i) out[i] = hw_radiance_one(sky, cos_theta, gamma, cos_gamma, wl[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PTC_NW; ++i) out[i] = 0.0f;
+    }
+}
+
+}  // namespace ptc
+#endif

@@ -49,8 +49,8 @@ def soup_scene(n, sky=None, seed=SOUP_SEED, nodes=None):
 
 
 def box_triangles():
-    """"box-12": a 2x2x2 room (12 triangles, open towards the camera is NOT needed: camera sits
-    inside) centred at z=-3 plus a 2-triangle emitter under the ceiling."""
+    """"box-12": a 2x2x2 room centred at z=-3, open towards the camera (5 walls = 10 triangles)
+    plus a 2-triangle emitter under the ceiling."""
     x0, x1, y0, y1, z0, z1 = -1.0, 1.0, -1.0, 1.0, -4.0, -2.0
     v = lambda x, y, z: (x, y, z)
     quads = [
@@ -59,7 +59,6 @@ def box_triangles():
         (v(x1, y0, z0), v(x1, y0, z1), v(x1, y1, z1), v(x1, y1, z0), 3),   # right
         (v(x0, y0, z1), v(x1, y0, z1), v(x1, y0, z0), v(x0, y0, z0), 4),   # floor
         (v(x0, y1, z0), v(x1, y1, z0), v(x1, y1, z1), v(x0, y1, z1), 4),   # ceiling
-        (v(x0, y0, z1), v(x0, y1, z1), v(x1, y1, z1), v(x1, y0, z1), 4),   # front (behind nothing; closes the box)
         (v(-0.3, 0.98, -3.3), v(0.3, 0.98, -3.3), v(0.3, 0.98, -2.7), v(-0.3, 0.98, -2.7), 5),  # emitter
     ]
     tris = np.zeros(2 * len(quads), dtype=abi.TRIANGLE)

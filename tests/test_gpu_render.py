@@ -1,0 +1,110 @@
+"""Parity of the HIP wavefront integrator (pt_render through the C ABI) with the CPU oracle.
+
+Both sides draw the same counter-based samples (include/pt_rng.h) and run the same float operations
+in the same order (include/pt_math.h for transcendentals), so images are expected to be equal
+bit for bit; the asserted bar is: at most 0.1 % of pixels may differ at all (a differing pixel
+means a traversal tie was broken differently), and the mean relative XYZ error over the image
+must be <= 1e-4.  NaN pixels (the reference's sky model returns NaN for un-normalised camera
+rays that look towards the sun) must be NaN on both sides.
+"""
+import numpy as np
+import pytest
+
+from pathtracer_amd import abi, core, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def compare_images(got, want, what, max_diff_frac=1e-3, mean_rel=1e-4):
+    assert got.shape == want.shape
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert np.array_equal(gn, wn), f"{what}: NaN pattern differs in {(gn != wn).sum()} values"
+    g, w = np.where(gn, 0, got), np.where(wn, 0, want)
+    diff_px = (g != w).any(axis=-1)
+    frac = diff_px.mean()
+    rel = np.abs(g - w).sum() / max(np.abs(w).sum(), 1e-30)
+    assert frac <= max_diff_frac, f"{what}: {diff_px.sum()} pixels differ ({frac:.2e}), rel {rel:.2e}"
+    assert rel <= mean_rel, f"{what}: mean relative error {rel:.2e}"
+    return frac, rel
+
+
+def test_default_scene_is_black_with_alpha_one(oracle, gpu_ctx):
+    """configs[0]: empty TOML scene, 256x256, 4 spp -> XYZ = 0, alpha = 1."""
+    arr = workloads.empty_scene()
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 256, 256, 0, 4, 4, seed=1)
+    want = oracle.render(oracle.scene(arr), 256, 256, 0, 4, 4, seed=1)
+    assert np.array_equal(got, want)
+    assert (got[..., :3] == 0).all() and (got[..., 3] == 1).all()
+
+
+def test_box_scene(oracle, gpu_ctx):
+    arr = workloads.box_scene()
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 96, 64, 0, 4, 4, seed=3)
+    want = oracle.render(oracle.scene(arr), 96, 64, 0, 4, 4, seed=3)
+    assert want[..., 1].mean() > 0
+    compare_images(got, want, "box")
+    st = gpu_ctx.stats()
+    assert st.paths == 96 * 64 * 4 and st.segments >= st.paths
+
+
+@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT])
+def test_soup_with_hosek_wilkie_sky(oracle, gpu_ctx, mode):
+    arr = workloads.soup_scene(20_000, sky=workloads.hw_sky())
+    gpu_ctx.set_traversal(mode)
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 160, 90, 0, 4, 4, seed=1)
+    gpu_ctx.set_traversal(abi.PT_TRAVERSE_FAST)
+    want, cnt = oracle.render(oracle.scene(arr), 160, 90, 0, 4, 4, seed=1, count=True)
+    assert np.isfinite(want[..., 1]).mean() > 0.5 and np.nanmean(want[..., 1]) > 0
+    compare_images(got, want, f"soup+hw mode={mode}")
+    assert gpu_ctx.stats().segments == cnt[1]
+
+
+def test_sun_disc_and_sky_only(oracle, gpu_ctx):
+    """No geometry: every path is one evaluate_sky call; aim the camera so the solar disc is in view."""
+    sky = core.sky_hosek_wilkie(2.5, 0.2, (0.0, 1.0, 0.0), (0.0, 0.5, -1.0))
+    arr = abi.SceneArrays(np.zeros(0, dtype=abi.TRIANGLE), None, np.array([abi.default_material()], dtype=abi.MATERIAL), sky)
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 128, 128, 0, 2, 2, seed=9, sensor_width=2.0, focal_length=1.0)
+    want = oracle.render(oracle.scene(arr), 128, 128, 0, 2, 2, seed=9, sensor_width=2.0, focal_length=1.0)
+    assert np.nanmax(want[..., 1]) > 100 * np.nanmedian(want[..., 1][want[..., 1] > 0])   # the disc is there
+    compare_images(got, want, "sky only", max_diff_frac=0.0, mean_rel=0.0)
+
+
+def test_dissolve_textures_uv_and_vertex_normals(oracle, gpu_ctx):
+    rng = np.random.default_rng(5)
+    tris = workloads.soup_triangles(5_000)
+    tris["flags"] = np.where(np.arange(tris.size) % 2 == 0, abi.PT_TRI_HAS_UV | abi.PT_TRI_HAS_NORMALS, 0)
+    tris["uv"] = rng.uniform(-2, 2, size=(tris.size, 3, 2)).astype(np.float32)
+    tris["vertex_normals"] = rng.normal(size=(tris.size, 3, 3)).astype(np.float32)
+    mats = workloads.soup_materials()
+    mats[1]["base_dissolve"] = 0.5                                   # half of the hits pass through
+    mats[2]["diffuse"]["kind"] = abi.PT_TEX_NEAREST; mats[2]["diffuse"]["image"] = 0
+    mats[3]["dissolve"]["kind"] = abi.PT_TEX_NEAREST; mats[3]["dissolve"]["image"] = 1
+    mats[8]["absorption"]["kind"] = abi.PT_TEX_NEAREST; mats[8]["absorption"]["image"] = 0
+    images = [rng.uniform(0, 1, size=(7, 5, 3)).astype(np.float32), rng.uniform(0, 1, size=(4, 9)).astype(np.float32)]
+    arr = abi.SceneArrays(tris, core.bvh_build(tris), mats, core.sky_d65(0.5), images)
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 128, 72, 0, 4, 4, seed=11)
+    want = oracle.render(oracle.scene(arr), 128, 72, 0, 4, 4, seed=11)
+    compare_images(got, want, "materials")
+
+
+def test_sample_ranges_compose(oracle, gpu_ctx):
+    """PT_RENDER_SUM over [0,3) + [3,5) equals the 5-spp image up to f32 summation order, and each
+    partial equals the oracle's partial exactly."""
+    arr = workloads.box_scene()
+    gsc, osc = gpu_ctx.scene(arr), oracle.scene(arr)
+    a = gpu_ctx.render(gsc, 64, 48, 0, 3, 5, seed=2, mode=abi.PT_RENDER_SUM)
+    b = gpu_ctx.render(gsc, 64, 48, 3, 2, 5, seed=2, mode=abi.PT_RENDER_SUM)
+    compare_images(a, oracle.render(osc, 64, 48, 0, 3, 5, seed=2, mode=abi.PT_RENDER_SUM), "partial a")
+    compare_images(b, oracle.render(osc, 64, 48, 3, 2, 5, seed=2, mode=abi.PT_RENDER_SUM), "partial b")
+    assert (a[..., 3] == 3).all() and (b[..., 3] == 2).all()
+    from pathtracer_amd.sharding import finalize_sums
+    full = gpu_ctx.render(gsc, 64, 48, 0, 5, 5, seed=2)
+    np.testing.assert_allclose(finalize_sums(a + b), full, rtol=2e-6, atol=1e-9)
+
+
+def test_multi_pass_equals_single_pass(oracle, gpu_ctx):
+    """More samples than fit one pass at this resolution -> several passes; still equal to the oracle."""
+    arr = workloads.box_scene()
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 1024, 1024, 0, 6, 6, seed=4)
+    want = oracle.render(oracle.scene(arr), 1024, 1024, 0, 6, 6, seed=4)
+    compare_images(got, want, "multi-pass")

@@ -1,0 +1,142 @@
+"""Parity of the HIP closest-hit path (pt_trace_closest, through the C ABI) with the CPU oracle.
+
+Bar (north_star): hit triangle ids bit-exact, t within 1e-5 relative.  Because the kernels repeat
+the reference's float operations in the same order, t/u/v are in fact compared for exact equality.
+"""
+import numpy as np
+import pytest
+
+from pathtracer_amd import abi, core, workloads
+
+pytestmark = pytest.mark.gpu
+
+MODES = [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT]
+
+
+def bounce_rays(rng, hits, rays, n):
+    """Secondary rays as the integrator makes them: origin on a hit point, un-normalised direction
+    in [-2,2]^3-ish, start = the triangle just hit (scene.rs:355-356)."""
+    ok = np.flatnonzero(hits["tri"] != abi.PT_NO_TRIANGLE)
+    pick = rng.choice(ok, size=n)
+    out = np.zeros(n, dtype=abi.RAY)
+    out["o"] = rays["o"][pick] + rays["d"][pick] * hits["t"][pick, None]
+    out["d"] = rng.uniform(-1.0, 1.0, size=(n, 3)).astype(np.float32) * rng.uniform(0.01, 2.0, size=(n, 1)).astype(np.float32)
+    return out, hits["tri"][pick].astype(np.uint32)
+
+
+def assert_same_hits(got, want, what):
+    bad = np.flatnonzero(got["tri"] != want["tri"])
+    assert bad.size == 0, f"{what}: {bad.size} id mismatches, first at ray {bad[:5]}: got {got[bad[:5]]}, want {want[bad[:5]]}"
+    hit = want["tri"] != abi.PT_NO_TRIANGLE
+    rel = np.abs(got["t"][hit] - want["t"][hit]) / np.maximum(np.abs(want["t"][hit]), 1e-30)
+    assert (rel <= 1e-5).all(), f"{what}: t off by {rel.max()}"
+    # stronger than required: same operations in the same order -> same bits
+    assert np.array_equal(got["t"][hit], want["t"][hit]), what
+    assert np.array_equal(got["u"][hit], want["u"][hit]) and np.array_equal(got["v"][hit], want["v"][hit]), what
+
+
+@pytest.fixture(scope="module")
+def soup(oracle, gpu_ctx):
+    arr = workloads.soup_scene(200_000)
+    return arr, oracle.scene(arr), gpu_ctx.scene(arr)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_primary_rays(oracle, gpu_ctx, soup, mode):
+    arr, osc, gsc = soup
+    rays = core.gen_primary_rays(640, 360)
+    gpu_ctx.set_traversal(mode)
+    got = gpu_ctx.trace(gsc, rays)
+    want = oracle.trace(osc, rays)
+    assert (want["tri"] != abi.PT_NO_TRIANGLE).mean() > 0.9
+    assert_same_hits(got, want, f"primary mode={mode}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_bounce_rays_with_start(oracle, gpu_ctx, soup, mode):
+    arr, osc, gsc = soup
+    rng = np.random.default_rng(7)
+    prim = core.gen_primary_rays(320, 180)
+    first = oracle.trace(osc, prim)
+    rays, start = bounce_rays(rng, first, prim, 100_000)
+    gpu_ctx.set_traversal(mode)
+    got = gpu_ctx.trace(gsc, rays, start)
+    want = oracle.trace(osc, rays, start)
+    assert_same_hits(got, want, f"bounce mode={mode}")
+    # the start triangle is excluded by identity only (bvh.rs:329-335)
+    assert (got["tri"] != start).all()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_axis_aligned_and_degenerate_directions(oracle, gpu_ctx, soup, mode):
+    """Zero direction components give +-inf inverse directions and 0*inf = NaN in the slab test."""
+    arr, osc, gsc = soup
+    rng = np.random.default_rng(3)
+    n = 20_000
+    rays = np.zeros(n, dtype=abi.RAY)
+    rays["o"] = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32) + np.float32([0, 0, -3])
+    d = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    kill = rng.integers(0, 3, size=n)
+    d[np.arange(n), kill] = 0.0
+    d[: n // 4, (kill[: n // 4] + 1) % 3] = 0.0        # two zero components
+    d[:8] = 0.0                                          # all-zero direction
+    d[8:16] = np.float32([-0.0, 0.0, -1.0])
+    rays["d"] = d
+    gpu_ctx.set_traversal(mode)
+    assert_same_hits(gpu_ctx.trace(gsc, rays), oracle.trace(osc, rays), f"axis-aligned mode={mode}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_deep_stack_spills(oracle, gpu_ctx, mode):
+    """Heavily overlapping long triangles push the per-lane stack past the 8-entry LDS ring."""
+    tris = core.gen_soup(11, 3000, (-1, -1, -4), (1, 1, -2), 0.8, 0.0, 8)
+    arr = abi.SceneArrays(tris, core.bvh_build(tris), workloads.soup_materials(), core.sky_d65(0.0))
+    osc, gsc = oracle.scene(arr), gpu_ctx.scene(arr)
+    rays = core.gen_primary_rays(256, 256)
+    _, cnt = oracle.trace_globalbest_stats(osc, rays[:4096])
+    assert cnt[3] > 8, f"scene does not overflow the ring (max stack {cnt[3]})"
+    gpu_ctx.set_traversal(mode)
+    assert_same_hits(gpu_ctx.trace(gsc, rays), oracle.trace(osc, rays), f"deep mode={mode}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_reference_triangle_kats_on_device(gpu_ctx, mode):
+    """triangle.rs:130-216 through the kernels: one exact hit, four misses."""
+    def one(tri_pts, o, d):
+        t = np.zeros(1, dtype=abi.TRIANGLE)
+        t["a"], t["b"], t["c"] = tri_pts
+        arr = abi.SceneArrays(t, core.bvh_build(t), np.array([abi.default_material()], dtype=abi.MATERIAL), core.sky_d65(0.0))
+        sc = gpu_ctx.scene(arr)
+        r = np.zeros(1, dtype=abi.RAY)
+        r["o"], r["d"] = o, d
+        return gpu_ctx.trace(sc, r)[0]
+    gpu_ctx.set_traversal(mode)
+    third = np.float32(1.0) / np.float32(3.0)
+    front = ((0, 0, -1), (1, 0, -1), (0, 1, -1))
+    h = one(front, (third, third, 0), (0, 0, -1))
+    assert h["tri"] == 0 and h["t"] == np.float32(1.0) and h["u"] == third and h["v"] == third
+    two3 = np.float32(2.0) / np.float32(3.0)
+    assert one(((0, 0, 2), (1, 0, 2), (0, 1, 2)), (two3, two3, 0), (0, 0, 1))["tri"] == abi.PT_NO_TRIANGLE
+    assert one(front, (two3, two3, 0), (0, 0, 1))["tri"] == abi.PT_NO_TRIANGLE
+    assert one(front, (-two3, two3, 0), (0, 0, 1))["tri"] == abi.PT_NO_TRIANGLE
+    assert one(front, (two3, -two3, 0), (0, 0, 1))["tri"] == abi.PT_NO_TRIANGLE
+
+
+def test_empty_scene_and_empty_batch(gpu_ctx):
+    sc = gpu_ctx.scene(workloads.empty_scene())
+    rays = core.gen_primary_rays(64, 64)
+    got = gpu_ctx.trace(sc, rays)
+    assert (got["tri"] == abi.PT_NO_TRIANGLE).all()
+    assert gpu_ctx.trace(sc, rays[:0]).size == 0
+
+
+def test_bad_scene_is_an_error_code(gpu_ctx):
+    arr = workloads.soup_scene(100)
+    bad = abi.SceneArrays(arr.triangles, arr.nodes.copy(), arr.materials, arr.sky)
+    bad.nodes["child_l_index"][0] = 0          # self-loop: traversal would never terminate
+    with pytest.raises(core.PtError) as e:
+        gpu_ctx.scene(bad)
+    assert e.value.code == abi.PT_ERR_INVALID
+    bad2 = abi.SceneArrays(arr.triangles, arr.nodes[:-1], arr.materials, arr.sky)
+    with pytest.raises(core.PtError):
+        gpu_ctx.scene(bad2)

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Development aid: time pt_trace_closest_dev on soup-N primary rays in both traversal modes."""
+import argparse
+import ctypes as C
+import sys
+import time
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from pathtracer_amd import abi, core, workloads
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--tris", type=int, default=1_000_000)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--reps", type=int, default=10)
+a = ap.parse_args()
+
+t = time.time()
+arr = workloads.soup_scene(a.tris)
+print(f"scene built in {time.time()-t:.2f}s", flush=True)
+ctx = core.Context(0)
+sc = ctx.scene(arr)
+i = sc.info()
+print("info", i.n_triangles, i.n_internal_nodes, i.max_depth, i.device_bytes, flush=True)
+rays = core.gen_primary_rays(a.width, a.height)
+n = rays.size
+d_rays = torch.from_numpy(rays.view(np.float32).reshape(n, 8)).cuda()
+d_out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+res = {}
+for mode, name in ((abi.PT_TRAVERSE_FAST, "fast"), (abi.PT_TRAVERSE_EXACT, "exact")):
+    ctx.set_traversal(mode)
+    ms = []
+    for r in range(a.reps + 2):
+        ctx.trace_dev(sc, d_rays.data_ptr(), 0, n, d_out.data_ptr())
+        ms.append(ctx.stats().trace_ms)
+    ms = ms[2:]
+    res[name] = d_out.cpu().numpy().copy()
+    print(f"{name}: {np.mean(ms):.3f} ms (min {np.min(ms):.3f}) -> {n/np.mean(ms)/1e3:.1f} Mrays/s", flush=True)
+print("fast==exact ids:", np.array_equal(res["fast"][:, 0], res["exact"][:, 0]), "all:", np.array_equal(res["fast"], res["exact"]))
