@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes over bench.py.
+# Usage: tools/profile_bench.sh <tag> [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+ARGS="--steps 20 --warmup 2 --no-cpu-baseline $*"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1 || { echo "kernel-trace failed"; tail -5 $OUT/trace.log; exit 1; }
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE GRBM_COUNT" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum"; do
+  name=$(echo $pass | tr ' ' '_' | cut -c1-40)
+  timeout -s KILL 300 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -o $TAG -- python3 $R/bench.py $ARGS --spectral-spp 0 > $OUT/pmc_$name.log 2>&1 || { echo "pmc pass $pass failed"; tail -3 $OUT/pmc_$name.log; }
+done
+find $OUT -name "*.csv" | head -40
+python3 $R/tools/summarize_prof.py $OUT $TAG > $OUT/summary_$TAG.txt 2>&1
+cat $OUT/summary_$TAG.txt
