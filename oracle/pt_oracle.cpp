@@ -879,7 +879,7 @@ void pto_trace_brute(const pto_scene* sc, const pt_ray* rays, const uint32_t* st
 // (enter a child iff its entry distance < best; later hit wins ties).  counters[4] +=
 // {nodes, tris, sum of max stack depth, max stack depth}.
 void pto_trace_globalbest_stats(const pto_scene* sc, const pt_ray* rays, uint64_t n, pt_hit* out,
-                                uint64_t* counters) {
+                                uint64_t* counters, uint32_t* per_ray /* nullable: {nodes, tris, pops} per ray */) {
     const Scene& s = sc->s;
     uint64_t nodes = 0, tris = 0, sumdepth = 0, maxdepth = 0;
     std::vector<std::pair<uint32_t, float>> stack;
@@ -889,9 +889,12 @@ void pto_trace_globalbest_stats(const pto_scene* sc, const pt_ray* rays, uint64_
         float bt = INF;
         stack.clear();
         size_t md = 0;
+        const uint64_t nodes0 = nodes, tris0 = tris;
+        uint32_t pops = 0;
         if (!s.nodes.empty()) stack.push_back({0u, 0.0f});
         while (!stack.empty()) {
             auto [ni, tmin] = stack.back(); stack.pop_back();
+            pops++;
             if (!(bt > tmin)) continue;
             for (;;) {
                 const Node& nd = s.nodes[ni];
@@ -917,6 +920,7 @@ void pto_trace_globalbest_stats(const pto_scene* sc, const pt_ray* rays, uint64_
             }
         }
         if (out) out[i] = best;
+        if (per_ray) { per_ray[3 * i] = (uint32_t)(nodes - nodes0); per_ray[3 * i + 1] = (uint32_t)(tris - tris0); per_ray[3 * i + 2] = pops; }
         sumdepth += md; maxdepth = std::max<uint64_t>(maxdepth, md);
     }
     counters[0] += nodes; counters[1] += tris; counters[2] += sumdepth;

@@ -8,8 +8,10 @@
 // spectral tables are copied to HBM once.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -74,6 +76,14 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
         if ((e = hipEventCreate(&ev)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
     if ((e = hipHostMalloc((void**)&ctx->h_counters, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    if ((e = hipMalloc((void**)&ctx->ticket, 256)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    auto env_u32 = [](const char* name, uint32_t def) {
+        const char* v = getenv(name);
+        return v ? (uint32_t)strtoul(v, nullptr, 10) : def;
+    };
+    ctx->tune_variant = env_u32("PTC_TRACE_VARIANT", ctx->tune_variant);
+    ctx->tune_blocks_per_cu = std::max(1u, std::min(8u, env_u32("PTC_BLOCKS_PER_CU", ctx->tune_blocks_per_cu)));
+    ctx->tune_refill = env_u32("PTC_REFILL", ctx->tune_refill);
     *out = ctx.release();
     return PT_OK;
 }
@@ -86,6 +96,7 @@ extern "C" void pt_shutdown(pt_ctx* ctx) {
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->io) (void)hipFree(ctx->io);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->ticket) (void)hipFree(ctx->ticket);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

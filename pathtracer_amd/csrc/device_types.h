@@ -84,6 +84,11 @@ struct pt_ctx {
     void* work = nullptr;       size_t work_bytes = 0;
     void* io = nullptr;         size_t io_bytes = 0;
     uint32_t* h_counters = nullptr;      // pinned
+    uint32_t* ticket = nullptr;          // device word: ray-block ticket counter of the persistent kernel
+    // tuning knobs (defaults chosen by measurement; PTC_* environment variables override)
+    uint32_t tune_variant = 1;           // 0: one batch of rays per wave pass, 1: persistent refill
+    uint32_t tune_blocks_per_cu = 8;
+    uint32_t tune_refill = 16;
 };
 
 int ptc_fail(pt_ctx* ctx, int code, const std::string& msg);

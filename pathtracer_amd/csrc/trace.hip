@@ -88,28 +88,36 @@ __device__ __forceinline__ bool tri_test(const DRay& r, float4 t0, float4 t1, fl
 }
 
 // ---- per-lane ring stack: LDS window over an HBM column -----------------------------------------
+// `ring` is the block's __shared__ array, slot-major ([slot][thread]); the column is
+// [depth][thread] in HBM.  LDS and HBM accesses are kept in separate, differently-flavoured
+// branches on purpose: if both sides were plain loads the compiler would select between the two
+// ADDRESSES and emit one flat_load, which is far slower than ds_read_b64.
 template <int S>
 struct LaneStack {
-    uint2* lds;          // &ring[0][tid]; slot stride = PTC_BLOCK
     uint2* spill;        // &column[0][gtid]; depth stride = spill_stride
     uint32_t spill_stride;
     uint32_t sp;         // logical size
     uint32_t base;       // entries [0, base) live in HBM, [base, sp) in LDS
 
     __device__ __forceinline__ void reset() { sp = 0u; base = 0u; }
-    __device__ __forceinline__ void push(uint32_t a, uint32_t b) {
-        if (sp - base == (uint32_t)S) {
-            spill[(size_t)base * spill_stride] = lds[(base % S) * PTC_BLOCK];
+    __device__ __forceinline__ void push(uint2* __restrict__ ring, uint32_t a, uint32_t b) {
+        if (__builtin_expect(sp - base == (uint32_t)S, 0)) {
+            const uint2 old = ring[(base % S) * PTC_BLOCK + threadIdx.x];
+            __builtin_nontemporal_store(old.x, &spill[(size_t)base * spill_stride].x);
+            __builtin_nontemporal_store(old.y, &spill[(size_t)base * spill_stride].y);
             base += 1u;
         }
-        lds[(sp % S) * PTC_BLOCK] = make_uint2(a, b);
+        ring[(sp % S) * PTC_BLOCK + threadIdx.x] = make_uint2(a, b);
         sp += 1u;
     }
-    __device__ __forceinline__ uint2 pop() {     // caller checks sp > 0
+    __device__ __forceinline__ uint2 pop(const uint2* __restrict__ ring) {     // caller checks sp > 0
         sp -= 1u;
-        if (sp >= base) return lds[(sp % S) * PTC_BLOCK];
+        if (__builtin_expect(sp >= base, 1)) return ring[(sp % S) * PTC_BLOCK + threadIdx.x];
         base = sp;
-        return spill[(size_t)sp * spill_stride];
+        uint2 e;
+        e.x = __builtin_nontemporal_load(&spill[(size_t)sp * spill_stride].x);
+        e.y = __builtin_nontemporal_load(&spill[(size_t)sp * spill_stride].y);
+        return e;
     }
 };
 
@@ -119,6 +127,11 @@ __device__ __forceinline__ void load_node(const float4* nodes, uint32_t idx, flo
     q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
 }
 
+#define PTC_IDLE 0xFFFFFFFFu   /* "needs a pop": leaf bit set, never a valid triangle index */
+
+// FAST.  Every loop iteration runs three predicated phases, so a lane can visit a node, test the
+// leaf it descends into and pop its next subtree in ONE trip; the wave's trip count is then about
+// the largest per-lane node count instead of the sum of node, leaf and pop steps.
 template <int S, bool QUEUED>
 __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const float4* __restrict__ rays,
                                                          const uint32_t* __restrict__ start,
@@ -130,7 +143,6 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
     const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
     if (count_ptr) n = *count_ptr;
     LaneStack<S> st;
-    st.lds = &ring[threadIdx.x];
     st.spill = spill + gtid;
     st.spill_stride = total_threads;
 
@@ -144,22 +156,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
         uint32_t cur = sc.root_ref;
         bool alive = sc.n_tris != 0u;
         while (alive) {
-            if (cur & PTC_LEAF_BIT) {
-                const uint32_t tri = cur & PTC_INDEX_MASK;
-                if (tri != skip) {                                            // bvh.rs:329-330
-                    const float4* tp = sc.tris + (size_t)tri * 3u;
-                    float d, u, v;
-                    if (tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
-                        best_t = d; best_u = u; best_v = v; best_id = tri;
-                    }
-                }
-                // pop until something still worth entering
-                for (;;) {
-                    if (st.sp == 0u) { alive = false; break; }
-                    uint2 e = st.pop();
-                    if (best_t > __uint_as_float(e.y)) { cur = e.x; break; }
-                }
-            } else {
+            // ---- phase 1: internal node (bvh.rs:259-325) ----
+            if (!(cur & PTC_LEAF_BIT)) {
                 float4 q0, q1, q2, q3;
                 load_node(sc.nodes, cur, q0, q1, q2, q3);
                 float lt, rt;
@@ -168,25 +166,134 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
                 lh = lh && (best_t > lt);
                 rh = rh && (best_t > rt);
                 const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
-                if (lh && rh) {
-                    const bool left_first = lt < rt;                          // bvh.rs:266
-                    st.push(left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
-                    cur = left_first ? lref : rref;
-                } else if (lh) {
-                    cur = lref;
-                } else if (rh) {
-                    cur = rref;
-                } else {
-                    for (;;) {
-                        if (st.sp == 0u) { alive = false; break; }
-                        uint2 e = st.pop();
-                        if (best_t > __uint_as_float(e.y)) { cur = e.x; break; }
+                const bool left_first = lt < rt;                              // bvh.rs:266
+                if (lh && rh) st.push(ring, left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
+                cur = (lh && (left_first || !rh)) ? lref : (rh ? rref : PTC_IDLE);
+            }
+            // ---- phase 2: leaf (bvh.rs:327-336) ----
+            if ((cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
+                const uint32_t tri = cur & PTC_INDEX_MASK;
+                if (tri != skip) {                                            // bvh.rs:329-330
+                    const float4* tp = sc.tris + (size_t)tri * 3u;
+                    float d, u, v;
+                    if (tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
+                        best_t = d; best_u = u; best_v = v; best_id = tri;
                     }
                 }
+                cur = PTC_IDLE;
+            }
+            // ---- phase 3: pop until something is still worth entering ----
+            while (cur == PTC_IDLE) {
+                if (st.sp == 0u) { alive = false; break; }
+                const uint2 e = st.pop(ring);
+                if (best_t > __uint_as_float(e.y)) cur = e.x;
             }
         }
         out[i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
                             __float_as_uint(best_u), __float_as_uint(best_v));
+    }
+}
+
+// FAST, persistent form.  Traversal lengths have a heavy tail (soup-1M primaries: mean 51 node
+// visits per ray, but the slowest of 64 neighbouring rays needs 141), so a wave that waits for its
+// slowest lane keeps only ~1/3 of its lanes busy.  Here a lane that finishes its ray takes the next
+// one at once: each wave reserves blocks of 64 consecutive rays from a global ticket counter (one
+// atomic per 64 rays, fetched by lane 0 and broadcast) and hands them to idle lanes by ballot +
+// popcount rank, whenever at least REFILL lanes are idle.  Lanes only idle during the final drain.
+template <int S, bool QUEUED, int REFILL>
+__global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
+    DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
+    const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
+    uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket) {
+    __shared__ uint2 ring[S * PTC_BLOCK];
+    const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (count_ptr) n = *count_ptr;
+    LaneStack<S> st;
+    st.spill = spill + gtid;
+    st.spill_stride = total_threads;
+    st.reset();
+    if (sc.n_tris == 0u) {          // empty BVH: every ray misses (bvh.rs:364-368)
+        for (uint32_t k = gtid; k < n; k += total_threads) out[QUEUED ? queue[k] : k] = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
+        return;
+    }
+
+    uint32_t blk_next = 0u, blk_end = 0u;     // wave-uniform: unassigned part of the reserved block
+    bool exhausted = false;                    // wave-uniform: the ticket counter ran past n
+    bool has_ray = false;
+    DRay r = {};
+    uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE;
+    float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
+
+    for (;;) {
+        // ---- refill ----
+        const unsigned long long idle = __ballot(!has_ray);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!exhausted && (n_idle >= (uint32_t)REFILL || n_idle == 64u)) {
+            if (blk_next == blk_end) {
+                uint32_t base = 0u;
+                if (lane == 0u) base = atomicAdd(ticket, 64u);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) { exhausted = true; blk_next = blk_end = 0u; }
+                else { blk_next = base; blk_end = (n - base < 64u) ? n : base + 64u; }
+            }
+            const uint32_t avail = blk_end - blk_next;
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!has_ray && rank < avail) {
+                const uint32_t k = blk_next + rank;
+                ray_i = QUEUED ? queue[k] : k;
+                r = make_ray(rays[2u * ray_i], rays[2u * ray_i + 1u]);
+                skip = start ? start[ray_i] : PT_NO_TRIANGLE;
+                best_t = pt_inf(); best_u = 0.0f; best_v = 0.0f; best_id = PT_NO_TRIANGLE;
+                st.reset();
+                cur = sc.root_ref;
+                has_ray = true;
+            }
+            blk_next += (n_idle < avail) ? n_idle : avail;
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (exhausted) break;
+            continue;                      // block ran dry mid-refill: reserve another one
+        }
+        if (has_ray) {
+            // ---- phase 1: internal node (bvh.rs:259-325) ----
+            if (!(cur & PTC_LEAF_BIT)) {
+                float4 q0, q1, q2, q3;
+                load_node(sc.nodes, cur, q0, q1, q2, q3);
+                float lt, rt;
+                bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);
+                bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);
+                lh = lh && (best_t > lt);
+                rh = rh && (best_t > rt);
+                const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
+                const bool left_first = lt < rt;                              // bvh.rs:266
+                if (lh && rh) st.push(ring, left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
+                cur = (lh && (left_first || !rh)) ? lref : (rh ? rref : PTC_IDLE);
+            }
+            // ---- phase 2: leaf (bvh.rs:327-336) ----
+            if ((cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
+                const uint32_t tri = cur & PTC_INDEX_MASK;
+                if (tri != skip) {
+                    const float4* tp = sc.tris + (size_t)tri * 3u;
+                    float d, u, v;
+                    if (tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
+                        best_t = d; best_u = u; best_v = v; best_id = tri;
+                    }
+                }
+                cur = PTC_IDLE;
+            }
+            // ---- phase 3: pop; an empty stack ends the ray ----
+            while (cur == PTC_IDLE) {
+                if (st.sp == 0u) {
+                    out[ray_i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
+                                            __float_as_uint(best_u), __float_as_uint(best_v));
+                    has_ray = false;
+                    break;
+                }
+                const uint2 e = st.pop(ring);
+                if (best_t > __uint_as_float(e.y)) cur = e.x;
+            }
+        }
     }
 }
 
@@ -202,7 +309,6 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, cons
     const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
     if (count_ptr) n = *count_ptr;
     LaneStack<S> st;
-    st.lds = &ring[threadIdx.x];
     st.spill = spill + gtid;
     st.spill_stride = total_threads;
 
@@ -238,7 +344,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, cons
                     if (lh && rh) {                                           // bvh.rs:264-270
                         const bool left_first = lt < rt;
                         // A frame: far ref (tag bit clear) + far entry distance
-                        st.push(left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
+                        st.push(ring, left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
                         cur = left_first ? lref : rref;
                     } else if (lh) {
                         cur = lref;                                           // bvh.rs:308-315
@@ -251,13 +357,13 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, cons
                 }
             } else {
                 if (st.sp == 0u) { alive = false; break; }
-                const uint2 e = st.pop();
+                const uint2 e = st.pop(ring);
                 const bool is_b = ((e.x & PTC_FRAME_BIT) != 0u) && ((e.x & PTC_LEAF_BIT) == 0u);
                 if (!is_b) {
                     // near subtree returned `ret`; bvh.rs:280-285
                     const float first_distance = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
                     if (first_distance > __uint_as_float(e.y)) {
-                        st.push(PTC_FRAME_BIT | ret_id, __float_as_uint(ret_t));   // B frame keeps `first`
+                        st.push(ring, PTC_FRAME_BIT | ret_id, __float_as_uint(ret_t));   // B frame keeps `first`
                         cur = e.x;
                         descending = true;
                     }
@@ -292,9 +398,10 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, cons
 int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
                      const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out) {
     if (n == 0) return PT_OK;
+    if (n > 0xF0000000u) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "more than 0xF0000000 rays in one batch");
     const DevSceneView& v = scene->view;
-    // resident grid: 8 blocks of 256 per CU at most; fewer when the batch is small
-    uint32_t max_blocks = (uint32_t)ctx->n_cus * 8u;
+    // resident grid: waves_per_simd blocks of 256 per CU at most; fewer when the batch is small
+    uint32_t max_blocks = (uint32_t)ctx->n_cus * ctx->tune_blocks_per_cu;
     uint32_t blocks = (n + PTC_BLOCK - 1) / PTC_BLOCK;
     if (blocks > max_blocks) blocks = max_blocks;
     const uint32_t total_threads = blocks * PTC_BLOCK;
@@ -307,20 +414,24 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
     uint4* out = reinterpret_cast<uint4*>(d_out);
     uint2* spill = reinterpret_cast<uint2*>(ctx->spill);
     dim3 grid(blocks), block(PTC_BLOCK);
+#define PTC_LAUNCH(kern, ...) hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, v, rays, d_start, d_queue, d_count, n, out, spill, total_threads, ##__VA_ARGS__)
     if (ctx->traversal == PT_TRAVERSE_EXACT) {
-        if (d_queue)
-            hipLaunchKernelGGL((k_trace_exact<S, true>), grid, block, 0, ctx->stream, v, rays, d_start, d_queue,
-                               d_count, n, out, spill, total_threads);
-        else
-            hipLaunchKernelGGL((k_trace_exact<S, false>), grid, block, 0, ctx->stream, v, rays, d_start, d_queue,
-                               d_count, n, out, spill, total_threads);
+        if (d_queue) PTC_LAUNCH((k_trace_exact<S, true>));
+        else PTC_LAUNCH((k_trace_exact<S, false>));
+    } else if (ctx->tune_variant == 0) {
+        if (d_queue) PTC_LAUNCH((k_trace_fast<S, true>));
+        else PTC_LAUNCH((k_trace_fast<S, false>));
     } else {
-        if (d_queue)
-            hipLaunchKernelGGL((k_trace_fast<S, true>), grid, block, 0, ctx->stream, v, rays, d_start, d_queue,
-                               d_count, n, out, spill, total_threads);
-        else
-            hipLaunchKernelGGL((k_trace_fast<S, false>), grid, block, 0, ctx->stream, v, rays, d_start, d_queue,
-                               d_count, n, out, spill, total_threads);
+        rc = ptc_hip(ctx, hipMemsetAsync(ctx->ticket, 0, sizeof(uint32_t), ctx->stream), "ticket reset");
+        if (rc != PT_OK) return rc;
+        const bool q = d_queue != nullptr;
+        switch (ctx->tune_refill) {
+            case 8:  if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 8>), ctx->ticket);  else PTC_LAUNCH((k_trace_fast_persistent<S, false, 8>), ctx->ticket);  break;
+            case 24: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 24>), ctx->ticket); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 24>), ctx->ticket); break;
+            case 32: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 32>), ctx->ticket); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 32>), ctx->ticket); break;
+            default: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 16>), ctx->ticket); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 16>), ctx->ticket); break;
+        }
     }
+#undef PTC_LAUNCH
     return ptc_hip(ctx, hipGetLastError(), "trace kernel launch");
 }

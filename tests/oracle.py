@@ -64,7 +64,7 @@ class Oracle:
             "pto_scene_get_nodes": (None, [vp, vp]),
             "pto_trace": (None, [vp, vp, vp, u64, vp, C.POINTER(u64), i32]),
             "pto_trace_brute": (None, [vp, vp, vp, u64, vp, i32]),
-            "pto_trace_globalbest_stats": (None, [vp, vp, u64, vp, C.POINTER(u64)]),
+            "pto_trace_globalbest_stats": (None, [vp, vp, u64, vp, C.POINTER(u64), vp]),
             "pto_evaluate_sky": (None, [vp, pf, pf, pf]),
             "pto_render": (None, [vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp, C.POINTER(u64), i32]),
             "pto_math": (f32, [i32, f32]),
@@ -167,12 +167,13 @@ class Oracle:
         self.L.pto_trace_brute(scene.handle, abi.ptr(rays), abi.ptr(st), rays.size, abi.ptr(out), self.nthreads)
         return out
 
-    def trace_globalbest_stats(self, scene, rays):
+    def trace_globalbest_stats(self, scene, rays, per_ray=False):
         rays = np.ascontiguousarray(rays, dtype=abi.RAY)
         out = np.zeros(rays.size, dtype=abi.HIT)
         cnt = (C.c_uint64 * 4)(0, 0, 0, 0)
-        self.L.pto_trace_globalbest_stats(scene.handle, abi.ptr(rays), rays.size, abi.ptr(out), cnt)
-        return out, list(cnt)
+        pr = np.zeros((rays.size, 3), dtype=np.uint32) if per_ray else None
+        self.L.pto_trace_globalbest_stats(scene.handle, abi.ptr(rays), rays.size, abi.ptr(out), cnt, abi.ptr(pr))
+        return (out, list(cnt), pr) if per_ray else (out, list(cnt))
 
     def evaluate_sky(self, scene, d, wl):
         out = (C.c_float * 8)()

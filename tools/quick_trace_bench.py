@@ -17,6 +17,7 @@ ap.add_argument("--tris", type=int, default=1_000_000)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--tile", type=int, default=0, help="reorder rays into TxT pixel tiles")
 a = ap.parse_args()
 
 t = time.time()
@@ -27,6 +28,11 @@ sc = ctx.scene(arr)
 i = sc.info()
 print("info", i.n_triangles, i.n_internal_nodes, i.max_depth, i.device_bytes, flush=True)
 rays = core.gen_primary_rays(a.width, a.height)
+if a.tile:
+    T = a.tile
+    ys, xs = np.mgrid[0:a.height, 0:a.width]
+    key = ((ys // T) * ((a.width + T - 1) // T) + (xs // T)) * (T * T) + (ys % T) * T + (xs % T)
+    rays = rays[np.argsort(key.ravel(), kind="stable")]
 n = rays.size
 d_rays = torch.from_numpy(rays.view(np.float32).reshape(n, 8)).cuda()
 d_out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
