@@ -112,11 +112,17 @@ struct LaneStack {
     }
     __device__ __forceinline__ uint2 pop(const uint2* __restrict__ ring) {     // caller checks sp > 0
         sp -= 1u;
-        if (__builtin_expect(sp >= base, 1)) return ring[(sp % S) * PTC_BLOCK + threadIdx.x];
-        base = sp;
-        uint2 e;
-        e.x = __builtin_nontemporal_load(&spill[(size_t)sp * spill_stride].x);
-        e.y = __builtin_nontemporal_load(&spill[(size_t)sp * spill_stride].y);
+        // the LDS read is unconditional (its slot always exists) so that it stays a ds_read_b64;
+        // the rare HBM refill overrides it
+        uint2 e = ring[(sp % S) * PTC_BLOCK + threadIdx.x];
+        if (__builtin_expect(sp < base, 0)) {
+            base = sp;
+            // volatile: keeps this a separate global load (otherwise LLVM selects between the LDS
+            // and HBM ADDRESSES and emits one slow flat_load for every pop)
+            const volatile uint32_t* col = reinterpret_cast<const volatile uint32_t*>(&spill[(size_t)sp * spill_stride]);
+            e.x = col[0];
+            e.y = col[1];
+        }
         return e;
     }
 };
