@@ -10,7 +10,8 @@ import numpy as np
 
 from . import abi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptcore.so")
+# PTCORE_LIB: development override used to A/B experimental builds of the same library
+_LIB_PATH = os.environ.get("PTCORE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptcore.so")
 _lib = None
 
 

@@ -46,6 +46,16 @@ int ptc_reserve(pt_ctx* ctx, void** buf, size_t* have, size_t need, const char* 
     return PT_OK;
 }
 
+int ptc_timed_event(pt_ctx* ctx, size_t i) {
+    while (ctx->trace_ev.size() <= i) {
+        hipEvent_t e = nullptr;
+        int rc = ptc_hip(ctx, hipEventCreate(&e), "hipEventCreate");
+        if (rc != PT_OK) return rc;
+        ctx->trace_ev.push_back(e);
+    }
+    return ptc_hip(ctx, hipEventRecord(ctx->trace_ev[i], ctx->stream), "hipEventRecord");
+}
+
 extern "C" int pt_abi_version(void) { return PT_ABI_VERSION; }
 
 extern "C" const char* pt_last_error(const pt_ctx* ctx) {
@@ -74,9 +84,12 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
         return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
     for (auto& ev : ctx->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    for (auto& ev : ctx->count_ev)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
     if ((e = hipHostMalloc((void**)&ctx->h_counters, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
     if ((e = hipMalloc((void**)&ctx->ticket, 256)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    if ((e = hipMemset(ctx->ticket, 0, 256)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
     auto env_u32 = [](const char* name, uint32_t def) {
         const char* v = getenv(name);
         return v ? (uint32_t)strtoul(v, nullptr, 10) : def;
@@ -84,6 +97,7 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_variant = env_u32("PTC_TRACE_VARIANT", ctx->tune_variant);
     ctx->tune_blocks_per_cu = std::max(1u, std::min(8u, env_u32("PTC_BLOCKS_PER_CU", ctx->tune_blocks_per_cu)));
     ctx->tune_refill = env_u32("PTC_REFILL", ctx->tune_refill);
+    ctx->tune_pass_paths = std::max(1u << 16, std::min(64u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
     *out = ctx.release();
     return PT_OK;
 }
@@ -98,6 +112,8 @@ extern "C" void pt_shutdown(pt_ctx* ctx) {
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->count_ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->trace_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

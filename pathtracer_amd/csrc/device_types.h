@@ -75,6 +75,9 @@ struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t count_ev[8] = {};         // pt_render: one per in-flight live-count readback
+    std::vector<hipEvent_t> trace_ev;    // pt_render: pairs around every traversal launch (grown on demand)
+    uint32_t launch_parity = 0;          // which of the two ticket words the next persistent launch uses
     uint32_t traversal = PT_TRAVERSE_FAST;
     std::string error;
     pt_stats stats{};
@@ -89,11 +92,14 @@ struct pt_ctx {
     uint32_t tune_variant = 1;           // 0: one batch of rays per wave pass, 1: persistent refill
     uint32_t tune_blocks_per_cu = 8;
     uint32_t tune_refill = 16;
+    uint32_t tune_pass_paths = 32u << 20; // pt_render: paths in flight per pass (~1.1 KiB of HBM each)
 };
 
 int ptc_fail(pt_ctx* ctx, int code, const std::string& msg);
 int ptc_hip(pt_ctx* ctx, hipError_t e, const char* what);
 int ptc_reserve(pt_ctx* ctx, void** buf, size_t* have, size_t need, const char* what);
+// records ctx->trace_ev[i] on the context's stream, creating events up to i on first use
+int ptc_timed_event(pt_ctx* ctx, size_t i);
 
 #define PTC_HIP(ctx, call)                                            \
     do {                                                              \

@@ -7,8 +7,9 @@
 //   material.rs:255-297  Material::sample (dissolve test, normal, Lambert sphere offset, emission)
 //
 // One PASS renders `spp_pass` consecutive sample indices of every pixel at once: path id
-// p = s_local * (W*H) + pixel.  Per-path state lives in HBM as structure-of-arrays indexed by the
-// path id; QUEUES hold the ids of live paths.  Each iteration the traversal kernel (trace.hip)
+// p = s_local * (W*H) + pixel.  Per-path state lives in HBM indexed by the path id, packed so that
+// every access is a whole 8/16/64-byte record (after a few bounces the live paths are sparse in p,
+// and 4-byte columns would touch one cache line per value); QUEUES hold the ids of live paths.  Each iteration the traversal kernel (trace.hip)
 // extends every queued ray, then the shade kernel consumes the hits, pushes one {weight, emit}
 // vertex per scatter into the path's vertex column and appends surviving paths to the next queue
 // with a wave-level ballot/prefix compaction (one atomic per wave).
@@ -29,33 +30,46 @@
 #include "../../include/pt_rng.h"
 
 #define PTC_BLOCK 256
+#ifndef PTC_SHADE_WAVES
+#define PTC_SHADE_WAVES 4        /* min waves per SIMD asked of the compiler for k_shade */
+#endif
 #define PTC_MAX_VERTS 16        /* ArrayVec<_, 16>, scene.rs:324 */
 #define PTC_MAX_ITERS 1024u     /* scene.rs:328 */
 
 namespace {
 
 struct PassState {
-    float4*   rays;       // [P][2]  pt_ray layout (origin, direction), consumed by trace.hip
+    float4*   rays;       // [P][2]  {origin.xyz, bits(start triangle)}, {direction.xyz, hero wavelength offset}:
+                          //         pt_ray layout with the two pads in use; trace.hip reads the start from pad0
     uint4*    hits;       // [P]
-    uint32_t* start;      // [P]  triangle the ray leaves (Option<&Triangle> start)
-    uint32_t* rng_index;  // [P]  draws consumed so far by the path's stream
-    uint32_t* len_iter;   // [P]  len | iterations << 8
-    float*    hero;       // [P]
-    float*    verts;      // [16][2][8][P]: vertex k, {weight, emit}, wavelength i, path p
+    uint2*    state;      // [P]  {draws consumed so far by the path's stream, len | iterations << 8}
+    float4*   verts;      // [P][16][4]: vertex k of path p = {weight[0..3], weight[4..7], emit[0..3], emit[4..7]},
+                          //         one 64-byte line per scatter event, written by one lane
     uint32_t* queue[2];   // [P] each
-    uint32_t* counts;     // [2] live-path counters of the two queues
+    uint32_t* miss_queue; // [P] paths whose ray left the scene; their sky term is evaluated once per pass (k_sky)
+    uint32_t* counts;     // [4]: [0..2] rotating live-path counters (iteration i reads [i%3], fills [(i+1)%3],
+                          //      clears [(i+2)%3]); [3] = length of miss_queue
     uint32_t  P;          // paths in this pass
     uint32_t  npix;
 };
 
-__device__ __forceinline__ size_t vert_index(uint32_t k, uint32_t which, uint32_t i, uint32_t p, uint32_t P) {
-    return ((size_t)((k * 2u + which) * PTC_NW + i)) * P + p;
+__device__ __forceinline__ float4* vert_ptr(const PassState& st, uint32_t p, uint32_t k) {
+    return st.verts + ((size_t)p * PTC_MAX_VERTS + k) * 4u;
+}
+__device__ __forceinline__ void store_vertex(const PassState& st, uint32_t p, uint32_t k, const float w[PTC_NW],
+                                             const float e[PTC_NW]) {
+    float4* v = vert_ptr(st, p, k);
+    v[0] = make_float4(w[0], w[1], w[2], w[3]);
+    v[1] = make_float4(w[4], w[5], w[6], w[7]);
+    v[2] = make_float4(e[0], e[1], e[2], e[3]);
+    v[3] = make_float4(e[4], e[5], e[6], e[7]);
 }
 
 // ---- generate: main.rs:76-89 -----------------------------------------------------------------------
 __global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera cam, uint64_t seed,
                                                        uint32_t sample_base) {
     const uint32_t p = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    if (p == 0u) { st.counts[0] = st.P; st.counts[1] = 0u; st.counts[2] = 0u; st.counts[3] = 0u; }
     if (p >= st.P) return;
     const uint32_t pixel = p % st.npix;
     const uint32_t sample = sample_base + p / st.npix;
@@ -72,43 +86,36 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera 
     const float dy = -((y + 0.5f) * sy - 0.5f) * sensor1;
     const float dz = -cam.focal_length;
     const float hero = pt_rng_uniform(&rng, 0.0f, pt_uniform_scale(0.0f, (830.0f - 360.0f) / (float)PTC_NW));  // main.rs:83-84
-    st.rays[2u * p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    st.rays[2u * p + 1u] = make_float4(dx, dy, dz, 0.0f);
-    st.start[p] = PT_NO_TRIANGLE;
-    st.rng_index[p] = rng.index;
-    st.len_iter[p] = 0u;
-    st.hero[p] = hero;
+    st.rays[2u * p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PT_NO_TRIANGLE));
+    st.rays[2u * p + 1u] = make_float4(dx, dy, dz, hero);
+    st.state[p] = make_uint2(rng.index, 0u);
     st.queue[0][p] = p;
 }
 
 // ---- shade: one iteration of the loop body scene.rs:333-368 ------------------------------------------
-__global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, const DevSky* __restrict__ sky, PassState st,
-                                                    uint32_t cur, uint32_t count, uint64_t seed,
-                                                    uint32_t sample_base) {
+// The live count is read from the device (st.counts[cin]) so that the host never has to wait for it:
+// the grid is sized for an upper bound and surplus threads only take part in the ballots.
+__global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState st, uint32_t cur, uint32_t cin,
+                                                    uint64_t seed, uint32_t sample_base) {
     const uint32_t k = blockIdx.x * PTC_BLOCK + threadIdx.x;
-    bool cont = false;
+    const uint32_t count = st.counts[cin];
+    uint32_t* const next_count = &st.counts[cin == 2u ? 0u : cin + 1u];
+    if (k == 0u) st.counts[cin == 0u ? 2u : cin - 1u] = 0u;     // the counter the NEXT iteration fills
+    bool cont = false, missed = false;
     uint32_t p = 0u;
     if (k < count) {
         p = st.queue[cur][k];
         const uint4 hit = st.hits[p];
-        const float4 ro = st.rays[2u * p], rd = st.rays[2u * p + 1u];
-        uint32_t li = st.len_iter[p];
-        uint32_t len = li & 0xFFu, iter = li >> 8;
-        float wl[PTC_NW];
-        ptc::wavelengths(st.hero[p], wl);
-        const uint32_t P = st.P;
-
         if (hit.x == PT_NO_TRIANGLE) {
-            // miss: push {0, sky} and stop (scene.rs:362-367)
-            float e[PTC_NW];
-            ptc::evaluate_sky(sc, sky, rd.x, rd.y, rd.z, wl, e);
-#pragma unroll
-            for (int i = 0; i < PTC_NW; ++i) {
-                st.verts[vert_index(len, 0u, i, p, P)] = 0.0f;
-                st.verts[vert_index(len, 1u, i, p, P)] = e[i];
-            }
-            len += 1u;
+            // miss: the path ends with {0, sky} (scene.rs:362-367); the sky term is evaluated by k_sky,
+            // once per pass over all such paths, so that this kernel's lanes do not wait for it
+            missed = true;
         } else {
+            const float4 ro = st.rays[2u * p], rd = st.rays[2u * p + 1u];
+            const uint2 state = st.state[p];
+            uint32_t len = state.y & 0xFFu, iter = state.y >> 8;
+            float wl[PTC_NW];
+            ptc::wavelengths(rd.w, wl);
             const uint32_t tri = hit.x;
             const float dist = __uint_as_float(hit.y), hu = __uint_as_float(hit.z), hv = __uint_as_float(hit.w);
             const float4* srec = sc.shade + (size_t)tri * 5u;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, const DevS
                 v = w0 * s0.w + hu * s1.y + hv * s1.w;
             }
             pt_rng rng;
-            pt_rng_init(&rng, seed, p % st.npix, sample_base + p / st.npix, st.rng_index[p]);
+            pt_rng_init(&rng, seed, p % st.npix, sample_base + p / st.npix, state.x);
             float dis = m.dissolve_value;
             if (m.dissolve_img != 0xFFFFFFFFu) {
                 float g, b; const float flat[3] = {dis, dis, dis};
@@ -132,8 +139,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, const DevS
             const float px = ro.x + rd.x * dist, py = ro.y + rd.y * dist, pz = ro.z + rd.z * dist;   // material.rs:292
             if (pt_rng_f32(&rng) >= m.base_dissolve * dis) {                    // material.rs:275
                 // dissolved: pass straight through (scene.rs:357-361)
-                st.rays[2u * p] = make_float4(px, py, pz, 0.0f);
-                st.start[p] = tri;
+                st.rays[2u * p] = make_float4(px, py, pz, __uint_as_float(tri));
                 cont = true;
             } else {
                 float nx, ny, nz;
@@ -182,37 +188,55 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, const DevS
                         for (int i = 0; i < PTC_NW; ++i) weight[i] = 0.0f;
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < PTC_NW; ++i) {
-                    st.verts[vert_index(len, 0u, i, p, P)] = weight[i];
-                    st.verts[vert_index(len, 1u, i, p, P)] = emit[i];
-                }
+                store_vertex(st, p, len, weight, emit);
                 len += 1u;
                 if (survive) {                                                  // scene.rs:354-356
-                    st.rays[2u * p] = make_float4(px, py, pz, 0.0f);
-                    st.rays[2u * p + 1u] = make_float4(ndx, ndy, ndz, 0.0f);
-                    st.start[p] = tri;
+                    st.rays[2u * p] = make_float4(px, py, pz, __uint_as_float(tri));
+                    st.rays[2u * p + 1u] = make_float4(ndx, ndy, ndz, rd.w);
                     cont = true;
                 }
             }
-            st.rng_index[p] = rng.index;
+            iter += 1u;
+            // loop header: `for _ in 0..1024` and the capacity check scene.rs:328-331
+            cont = cont && (len < PTC_MAX_VERTS) && (iter < PTC_MAX_ITERS);
+            st.state[p] = make_uint2(rng.index, len | (iter << 8));
         }
-        iter += 1u;
-        // loop header: `for _ in 0..1024` and the capacity check scene.rs:328-331
-        cont = cont && (len < PTC_MAX_VERTS) && (iter < PTC_MAX_ITERS);
-        st.len_iter[p] = len | (iter << 8);
     }
-    // wave-level compaction into the next queue: ballot -> popcount prefix -> one atomic per wave
+    const uint32_t lane = threadIdx.x & 63u;
+    // misses -> miss queue, survivors -> next queue: ballot -> popcount prefix -> one atomic per wave
+    const unsigned long long mmask = __ballot(missed);
+    if (mmask != 0ull) {
+        const int leader = __ffsll((long long)mmask) - 1;
+        uint32_t base = 0u;
+        if ((int)lane == leader) base = atomicAdd(&st.counts[3], (uint32_t)__popcll(mmask));
+        base = __shfl(base, leader);
+        if (missed) st.miss_queue[base + (uint32_t)__popcll(mmask & ((1ull << lane) - 1ull))] = p;
+    }
     const unsigned long long mask = __ballot(cont);
     if (mask != 0ull) {
-        const uint32_t lane = threadIdx.x & 63u;
+        const int leader = __ffsll((long long)mask) - 1;
         uint32_t base = 0u;
-        if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) base = atomicAdd(&st.counts[cur ^ 1u], (uint32_t)__popcll(mask));
-        base = __shfl(base, __ffsll((long long)mask) - 1);
-        if (cont) {
-            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            st.queue[cur ^ 1u][base + rank] = p;
-        }
+        if ((int)lane == leader) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+        if (cont) st.queue[cur ^ 1u][base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
+    }
+}
+
+// ---- sky: Scene::evaluate_sky for every path of the pass that left the scene (scene.rs:362-367) ------
+__global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky* __restrict__ sky, PassState st) {
+    const uint32_t count = st.counts[3];
+    for (uint32_t k = blockIdx.x * PTC_BLOCK + threadIdx.x; k < count; k += gridDim.x * PTC_BLOCK) {
+        const uint32_t p = st.miss_queue[k];
+        const float4 rd = st.rays[2u * p + 1u];
+        const uint2 state = st.state[p];
+        const uint32_t len = state.y & 0xFFu;
+        float wl[PTC_NW], e[PTC_NW], zero[PTC_NW];
+        ptc::wavelengths(rd.w, wl);
+        ptc::evaluate_sky(sc, sky, rd.x, rd.y, rd.z, wl, e);
+#pragma unroll
+        for (int i = 0; i < PTC_NW; ++i) zero[i] = 0.0f;
+        store_vertex(st, p, len, zero, e);
+        st.state[p] = make_uint2(state.x, state.y + 1u);
     }
 }
 
@@ -221,20 +245,21 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_accumulate(PassState st, uint32_t
     const uint32_t pixel = blockIdx.x * PTC_BLOCK + threadIdx.x;
     if (pixel >= st.npix) return;
     float4 a = acc[pixel];
-    const uint32_t P = st.P;
     for (uint32_t s = 0; s < spp_pass; ++s) {
         const uint32_t p = s * st.npix + pixel;
-        const uint32_t len = st.len_iter[p] & 0xFFu;
+        const uint32_t len = st.state[p].y & 0xFFu;
+        const float hero = st.rays[2u * p + 1u].w;
         float L[PTC_NW];
 #pragma unroll
         for (int i = 0; i < PTC_NW; ++i) L[i] = 0.0f;
         for (uint32_t k = len; k-- > 0u;) {
-#pragma unroll
-            for (int i = 0; i < PTC_NW; ++i)
-                L[i] = L[i] * st.verts[vert_index(k, 0u, i, p, P)] + st.verts[vert_index(k, 1u, i, p, P)];
+            const float4* v = vert_ptr(st, p, k);
+            const float4 w0 = v[0], w1 = v[1], e0 = v[2], e1 = v[3];
+            L[0] = L[0] * w0.x + e0.x; L[1] = L[1] * w0.y + e0.y; L[2] = L[2] * w0.z + e0.z; L[3] = L[3] * w0.w + e0.w;
+            L[4] = L[4] * w1.x + e1.x; L[5] = L[5] * w1.y + e1.y; L[6] = L[6] * w1.z + e1.z; L[7] = L[7] * w1.w + e1.w;
         }
         float wl[PTC_NW];
-        ptc::wavelengths(st.hero[p], wl);
+        ptc::wavelengths(hero, wl);
 #pragma unroll
         for (int i = 0; i < PTC_NW; ++i) {
             float X, Y, Z;
@@ -275,8 +300,8 @@ extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera
     PTC_HIP(ctx, hipSetDevice(ctx->device));
     ctx->stats = pt_stats{};
 
-    // paths per pass: about 4M in flight (1 KiB of vertex column each), whole samples only
-    uint32_t spp_pass = (uint32_t)std::max<uint64_t>(1, (4ull << 20) / npix);
+    // paths per pass: ctx->tune_pass_paths in flight (1 KiB of vertex column each), whole samples only
+    uint32_t spp_pass = (uint32_t)std::max<uint64_t>(1, (uint64_t)ctx->tune_pass_paths / npix);
     if (spp_pass > spp_count) spp_pass = spp_count ? spp_count : 1u;
     const uint32_t Pmax = spp_pass * npix;
 
@@ -286,9 +311,8 @@ extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera
     const size_t o_acc = carve((size_t)npix * sizeof(float4));
     const size_t o_rays = carve((size_t)Pmax * 2 * sizeof(float4));
     const size_t o_hits = carve((size_t)Pmax * sizeof(uint4));
-    const size_t o_start = carve((size_t)Pmax * 4), o_rng = carve((size_t)Pmax * 4), o_li = carve((size_t)Pmax * 4);
-    const size_t o_hero = carve((size_t)Pmax * 4);
-    const size_t o_q0 = carve((size_t)Pmax * 4), o_q1 = carve((size_t)Pmax * 4);
+    const size_t o_state = carve((size_t)Pmax * sizeof(uint2));
+    const size_t o_q0 = carve((size_t)Pmax * 4), o_q1 = carve((size_t)Pmax * 4), o_qm = carve((size_t)Pmax * 4);
     const size_t o_cnt = carve(256);
     const size_t o_verts = carve((size_t)Pmax * PTC_MAX_VERTS * 2 * PTC_NW * sizeof(float));
     int rc = ptc_reserve(ctx, &ctx->work, &ctx->work_bytes, off, "render workspace");
@@ -297,18 +321,22 @@ extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera
     float4* acc = (float4*)(base + o_acc);
     PassState st{};
     st.rays = (float4*)(base + o_rays); st.hits = (uint4*)(base + o_hits);
-    st.start = (uint32_t*)(base + o_start); st.rng_index = (uint32_t*)(base + o_rng);
-    st.len_iter = (uint32_t*)(base + o_li); st.hero = (float*)(base + o_hero);
-    st.queue[0] = (uint32_t*)(base + o_q0); st.queue[1] = (uint32_t*)(base + o_q1);
-    st.counts = (uint32_t*)(base + o_cnt); st.verts = (float*)(base + o_verts);
+    st.state = (uint2*)(base + o_state);
+    st.queue[0] = (uint32_t*)(base + o_q0); st.queue[1] = (uint32_t*)(base + o_q1); st.miss_queue = (uint32_t*)(base + o_qm);
+    st.counts = (uint32_t*)(base + o_cnt); st.verts = (float4*)(base + o_verts);
     st.npix = npix;
 
     hipStream_t s = ctx->stream;
     PTC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
     PTC_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * sizeof(float4), s));
     const uint32_t pix_blocks = (npix + PTC_BLOCK - 1) / PTC_BLOCK;
-    double trace_ms = 0.0;
+    size_t n_timed = 0;               // trace launches bracketed by ctx->trace_ev[2i], [2i+1]
 
+    // The path loop runs AHEAD of the host: iteration i's kernels read the live count from the device,
+    // the count is copied back asynchronously and only consulted LOOKAHEAD iterations later to shrink
+    // the grids and to notice that every path has ended (at most LOOKAHEAD surplus iterations are
+    // enqueued; with a zero count their kernels return at once).
+    constexpr uint32_t LOOKAHEAD = 2, SLOTS = 8;
     for (uint32_t done = 0; done < spp_count; done += spp_pass) {
         const uint32_t this_spp = std::min(spp_pass, spp_count - done);
         const uint32_t P = this_spp * npix;
@@ -316,25 +344,41 @@ extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera
         st.P = P;
         hipLaunchKernelGGL(k_generate, dim3((P + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, st, *cam, seed, sample_base);
         ctx->stats.paths += P;
-        uint32_t live = P, cur = 0;
-        while (live != 0) {
-            PTC_HIP(ctx, hipMemsetAsync(&st.counts[cur ^ 1u], 0, sizeof(uint32_t), s));
-            PTC_HIP(ctx, hipEventRecord(ctx->ev[0], s));
-            rc = ptc_launch_trace(ctx, scene, (const pt_ray*)st.rays, st.start, st.queue[cur], nullptr, live, (pt_hit*)st.hits);
-            if (rc != PT_OK) return rc;
-            PTC_HIP(ctx, hipEventRecord(ctx->ev[1], s));
-            hipLaunchKernelGGL(k_shade, dim3((live + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, scene->view,
-                               scene->d_sky, st, cur, live, seed, sample_base);
-            PTC_HIP(ctx, hipMemcpyAsync(ctx->h_counters, &st.counts[cur ^ 1u], sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            PTC_HIP(ctx, hipStreamSynchronize(s));
-            float ms = 0.0f;
-            PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-            trace_ms += ms;
-            ctx->stats.trace_rays += live;
-            ctx->stats.trace_launches += 1;
+        ctx->stats.segments += P;
+        uint32_t live_ub = P;             // upper bound of the live count of the next iteration to enqueue
+        uint32_t enq = 0, harvested = 0;  // iterations enqueued / counts read back
+        bool finished = false;
+        while (!finished) {
+            if (enq < PTC_MAX_ITERS && enq - harvested <= LOOKAHEAD) {
+                rc = ptc_timed_event(ctx, 2 * n_timed);
+                if (rc != PT_OK) return rc;
+                rc = ptc_launch_trace(ctx, scene, (const pt_ray*)st.rays, nullptr, st.queue[enq & 1u], &st.counts[enq % 3u],
+                                      live_ub, (pt_hit*)st.hits);
+                if (rc != PT_OK) return rc;
+                rc = ptc_timed_event(ctx, 2 * n_timed + 1);
+                if (rc != PT_OK) return rc;
+                n_timed += 1;
+                hipLaunchKernelGGL(k_shade, dim3((live_ub + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, scene->view,
+                                   st, enq & 1u, enq % 3u, seed, sample_base);
+                PTC_HIP(ctx, hipMemcpyAsync(&ctx->h_counters[enq % SLOTS], &st.counts[(enq + 1u) % 3u], sizeof(uint32_t),
+                                            hipMemcpyDeviceToHost, s));
+                PTC_HIP(ctx, hipEventRecord(ctx->count_ev[enq % SLOTS], s));
+                enq += 1;
+                continue;
+            }
+            // read back the oldest outstanding count (blocks only when the host is LOOKAHEAD ahead)
+            PTC_HIP(ctx, hipEventSynchronize(ctx->count_ev[harvested % SLOTS]));
+            const uint32_t live = ctx->h_counters[harvested % SLOTS];
+            harvested += 1;
             ctx->stats.segments += live;
-            live = ctx->h_counters[0];
-            cur ^= 1u;
+            live_ub = live;
+            if (live == 0u || harvested == PTC_MAX_ITERS) finished = true;
+        }
+        // counts of surplus iterations are zero; nothing to read.  The stream is in order, so the
+        // accumulate kernel sees every vertex column complete.
+        {
+            const uint32_t sky_blocks = std::min<uint32_t>((P + PTC_BLOCK - 1) / PTC_BLOCK, (uint32_t)ctx->n_cus * 16u);
+            hipLaunchKernelGGL(k_sky, dim3(sky_blocks), dim3(PTC_BLOCK), 0, s, scene->view, scene->d_sky, st);
         }
         hipLaunchKernelGGL(k_accumulate, dim3(pix_blocks), dim3(PTC_BLOCK), 0, s, st, this_spp, acc);
     }
@@ -346,8 +390,16 @@ extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera
     PTC_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
     float total = 0.0f;
     PTC_HIP(ctx, hipEventElapsedTime(&total, ctx->ev[2], ctx->ev[3]));
+    double trace_ms = 0.0;
+    for (size_t i = 0; i < n_timed; ++i) {
+        float ms = 0.0f;
+        PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->trace_ev[2 * i], ctx->trace_ev[2 * i + 1]));
+        trace_ms += ms;
+    }
     ctx->stats.total_ms = total;
     ctx->stats.trace_ms = trace_ms;
+    ctx->stats.trace_rays = ctx->stats.segments;
+    ctx->stats.trace_launches = (uint32_t)n_timed;
     return PT_OK;
 }
 

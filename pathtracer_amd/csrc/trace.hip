@@ -154,8 +154,10 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
 
     for (uint32_t k = gtid; k < n; k += total_threads) {
         const uint32_t i = QUEUED ? queue[k] : k;
-        const DRay r = make_ray(rays[2u * i], rays[2u * i + 1u]);
-        const uint32_t skip = start ? start[i] : PT_NO_TRIANGLE;
+        const float4 ro = rays[2u * i];
+        const DRay r = make_ray(ro, rays[2u * i + 1u]);
+        // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
+        const uint32_t skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[i] : PT_NO_TRIANGLE);
         float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
         uint32_t best_id = PT_NO_TRIANGLE;
         st.reset();
@@ -210,11 +212,15 @@ template <int S, bool QUEUED, int REFILL>
 __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
     DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
-    uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket) {
+    uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket,
+    uint32_t* __restrict__ ticket_next) {
     __shared__ uint2 ring[S * PTC_BLOCK];
     const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (count_ptr) n = *count_ptr;
+    // two ticket words alternate between launches; this launch clears the one the NEXT launch uses
+    // (the previous launch, its last user, has completed: launches are stream-ordered)
+    if (gtid == 0u) *ticket_next = 0u;
     LaneStack<S> st;
     st.spill = spill + gtid;
     st.spill_stride = total_threads;
@@ -248,8 +254,10 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
             if (!has_ray && rank < avail) {
                 const uint32_t k = blk_next + rank;
                 ray_i = QUEUED ? queue[k] : k;
-                r = make_ray(rays[2u * ray_i], rays[2u * ray_i + 1u]);
-                skip = start ? start[ray_i] : PT_NO_TRIANGLE;
+                const float4 ro = rays[2u * ray_i];
+                r = make_ray(ro, rays[2u * ray_i + 1u]);
+                // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
+                skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[ray_i] : PT_NO_TRIANGLE);
                 best_t = pt_inf(); best_u = 0.0f; best_v = 0.0f; best_id = PT_NO_TRIANGLE;
                 st.reset();
                 cur = sc.root_ref;
@@ -320,8 +328,10 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, cons
 
     for (uint32_t k = gtid; k < n; k += total_threads) {
         const uint32_t i = QUEUED ? queue[k] : k;
-        const DRay r = make_ray(rays[2u * i], rays[2u * i + 1u]);
-        const uint32_t skip = start ? start[i] : PT_NO_TRIANGLE;
+        const float4 ro = rays[2u * i];
+        const DRay r = make_ray(ro, rays[2u * i + 1u]);
+        // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
+        const uint32_t skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[i] : PT_NO_TRIANGLE);
         // value being returned up the (virtual) call stack: None = {NONE_ID, +inf}
         uint32_t ret_id = PTC_NONE_ID;
         float ret_t = pt_inf();
@@ -428,14 +438,15 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
         if (d_queue) PTC_LAUNCH((k_trace_fast<S, true>));
         else PTC_LAUNCH((k_trace_fast<S, false>));
     } else {
-        rc = ptc_hip(ctx, hipMemsetAsync(ctx->ticket, 0, sizeof(uint32_t), ctx->stream), "ticket reset");
-        if (rc != PT_OK) return rc;
+        uint32_t* const ticket = ctx->ticket + 32u * ctx->launch_parity;          // this launch's counter
+        uint32_t* const ticket_next = ctx->ticket + 32u * (ctx->launch_parity ^ 1u);
+        ctx->launch_parity ^= 1u;
         const bool q = d_queue != nullptr;
         switch (ctx->tune_refill) {
-            case 8:  if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 8>), ctx->ticket);  else PTC_LAUNCH((k_trace_fast_persistent<S, false, 8>), ctx->ticket);  break;
-            case 24: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 24>), ctx->ticket); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 24>), ctx->ticket); break;
-            case 32: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 32>), ctx->ticket); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 32>), ctx->ticket); break;
-            default: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 16>), ctx->ticket); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 16>), ctx->ticket); break;
+            case 8:  if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 8>), ticket, ticket_next);  else PTC_LAUNCH((k_trace_fast_persistent<S, false, 8>), ticket, ticket_next);  break;
+            case 24: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 24>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 24>), ticket, ticket_next); break;
+            case 32: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 32>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 32>), ticket, ticket_next); break;
+            default: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 16>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 16>), ticket, ticket_next); break;
         }
     }
 #undef PTC_LAUNCH
