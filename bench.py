@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spectral-spp", type=int, default=8, help="samples per pixel of the spectral leg (0 = skip)")
+    ap.add_argument("--spectral-spp", type=int, default=64, help="samples per pixel PER RANK of the spectral leg (config 3: 64; 0 = skip)")
     ap.add_argument("--traversal", choices=["fast", "exact"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -121,7 +121,9 @@ def main():
 
         if world > 1:   # warm the communicator
             dist.all_reduce(torch.zeros(1, device="cuda"))
-        ctx.render_dev(scene, a.width, a.height, 0, 1, 1, 1, abi.PT_RENDER_SUM, d_img.data_ptr())   # warm-up pass
+        # warm-up: one full-size pass, so that the pass workspace (about 1.1 KiB per path in flight) is
+        # allocated before the timed region
+        ctx.render_dev(scene, a.width, a.height, 0, min(a.spectral_spp, 16), spp_total, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
         barrier()
         t1 = time.perf_counter()
         buf = sharding.render_sharded(render_sum, spp_total, rank, world, all_reduce if world > 1 else None)
@@ -141,7 +143,9 @@ def main():
             "trace_share_of_device_time_rank0": st.trace_ms / max(st.total_ms, 1e-9),
             "allreduce_ms": reduce_ms[0] if world > 1 else None,
             "finite_pixel_fraction": float(torch.isfinite(img[..., 1]).float().mean()),
-            "config": {"workload": "soup-1M + Hosek-Wilkie sky (turbidity 3, albedo 0.3), 1920x1080, seed 1"},
+            "spp_per_rank": a.spectral_spp,
+            "config": {"workload": f"soup-{a.tris} + Hosek-Wilkie sky (turbidity 3, albedo 0.3), {a.width}x{a.height}, "
+                                   f"{spp_total} spp, seed 1 (BASELINE configs[2] at N=1)"},
         }
 
     # ---- CPU baseline + visit counts (rank 0, N = 1 only: bounded, about 10-30 s of CPU work) -------
@@ -177,19 +181,25 @@ def main():
     if n_node is not None:
         b_ray = 32 + 16 + 64 * n_node + 48 * n_tri
         achieved = b_ray * n / (kernel_ms_avg * 1e-3) / 1e9
-        traffic = None
+        # HBM-side bytes per launch from the PMC passes of tools/profile_bench.sh on this same command
+        # (profiles/traffic.json; null until that file matches this workload)
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("traversal") == a.traversal and tj.get("tris") == a.tris:
-                traffic = tj.get("hbm_bytes_per_launch")
+            if tj.get("traversal") == a.traversal and tj.get("tris") == a.tris and tj.get("rays") == n:
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         roofline = {
-            "bound": "hbm", "kernel": f"k_trace_{a.traversal}", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": achieved / 8000.0, "traffic": traffic,
+            "bound": "hbm", "kernel": "k_trace_fast_persistent" if a.traversal == "fast" else "k_trace_exact",
+            "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_ray": b_ray, "n_node": n_node, "n_tri": n_tri, "visit_counts": counts_src,
             "kernel_ms": kernel_ms_avg,
-            "note": "algorithmic bytes under the reference's traversal rule; the 112 MB node+triangle set is "
-                    "served from L2 / Infinity Cache, so the fraction can exceed what HBM alone could deliver",
+            "algorithmic_bytes_per_launch": b_ray * n,
+            "note": "achieved = algorithmic bytes (B_ray = 32 + 16 + 64*n_node + 48*n_tri under the REFERENCE's traversal "
+                    "rule, SURVEY.md 8d) / kernel time. The 112 MB node+triangle set is re-read from L1/L2/Infinity Cache, "
+                    "so measured HBM-side traffic is a small fraction of the algorithmic bytes and the kernel is bound by "
+                    "the vector-memory address path and VALU issue, not by HBM (DESIGN.md)",
         }
 
     if rank == 0:

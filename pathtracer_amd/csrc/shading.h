@@ -38,9 +38,14 @@ __device__ __forceinline__ float reflectance_at_one(const float* __restrict__ ta
     const float index = pt_floor(offset);
     const float alpha = offset - index;
     const uint32_t i = pt_f2usize(index);
-    float b0x = 0.0f, b0y = 0.0f, b0z = 0.0f, b1x = 0.0f, b1y = 0.0f, b1z = 0.0f;
-    if (i < 471u) { b0x = tab[3u * i]; b0y = tab[3u * i + 1u]; b0z = tab[3u * i + 2u]; }
-    if (i < 470u) { b1x = tab[3u * i + 3u]; b1y = tab[3u * i + 4u]; b1z = tab[3u * i + 5u]; }
+    // TABLE.get(i).unwrap_or([0.0; 3]) for rows i and i+1.  The loads are UNCONDITIONAL (clamped index,
+    // zero selected afterwards) so that the rows of all eight wavelengths can be in flight together
+    // instead of one guarded round trip after another.
+    const uint32_t i0 = i < 470u ? i : 470u, i1 = i < 469u ? i + 1u : 470u;
+    float b0x = tab[3u * i0], b0y = tab[3u * i0 + 1u], b0z = tab[3u * i0 + 2u];
+    float b1x = tab[3u * i1], b1y = tab[3u * i1 + 1u], b1z = tab[3u * i1 + 2u];
+    if (!(i < 471u)) { b0x = 0.0f; b0y = 0.0f; b0z = 0.0f; }
+    if (!(i < 470u)) { b1x = 0.0f; b1y = 0.0f; b1z = 0.0f; }
     const float w0 = 1.0f - alpha;
     const float bx = b0x * w0 + b1x * alpha;
     const float by = b0y * w0 + b1y * alpha;
@@ -53,8 +58,10 @@ __device__ __forceinline__ float d65_one(const float* __restrict__ tab, float wl
     const float index = pt_floor(offset);
     const float alpha = offset - index;
     const uint32_t i = pt_f2usize(index);
-    const float t0 = (i < 531u) ? tab[i] : 0.0f;
-    const float t1 = (i < 530u) ? tab[i + 1u] : 0.0f;
+    const uint32_t i0 = i < 530u ? i : 530u, i1 = i < 529u ? i + 1u : 530u;   // unconditional loads, as above
+    float t0 = tab[i0], t1 = tab[i1];
+    if (!(i < 531u)) t0 = 0.0f;
+    if (!(i < 530u)) t1 = 0.0f;
     return t0 * (1.0f - alpha) + t1 * alpha;
 }
 
