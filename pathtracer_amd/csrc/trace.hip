@@ -442,12 +442,17 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
         uint32_t* const ticket_next = ctx->ticket + 32u * (ctx->launch_parity ^ 1u);
         ctx->launch_parity ^= 1u;
         const bool q = d_queue != nullptr;
-        switch (ctx->tune_refill) {
-            case 8:  if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 8>), ticket, ticket_next);  else PTC_LAUNCH((k_trace_fast_persistent<S, false, 8>), ticket, ticket_next);  break;
-            case 24: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 24>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 24>), ticket, ticket_next); break;
-            case 32: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 32>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 32>), ticket, ticket_next); break;
-            default: if (q) PTC_LAUNCH((k_trace_fast_persistent<S, true, 16>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<S, false, 16>), ticket, ticket_next); break;
+#define PTC_PERS(SS, R) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, R>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, R>), ticket, ticket_next); } while (0)
+        switch (ctx->tune_ring * 100u + ctx->tune_refill) {
+            case 808:  PTC_PERS(8, 8); break;
+            case 824:  PTC_PERS(8, 24); break;
+            case 832:  PTC_PERS(8, 32); break;
+            case 1016: PTC_PERS(10, 16); break;
+            case 1616: PTC_PERS(16, 16); break;
+            case 816:  PTC_PERS(8, 16); break;
+            default:   PTC_PERS(12, 16); break;
         }
+#undef PTC_PERS
     }
 #undef PTC_LAUNCH
     return ptc_hip(ctx, hipGetLastError(), "trace kernel launch");
