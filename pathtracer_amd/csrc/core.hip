@@ -97,6 +97,7 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_variant = env_u32("PTC_TRACE_VARIANT", ctx->tune_variant);
     ctx->tune_blocks_per_cu = std::max(1u, std::min(8u, env_u32("PTC_BLOCKS_PER_CU", ctx->tune_blocks_per_cu)));
     ctx->tune_refill = env_u32("PTC_REFILL", ctx->tune_refill);
+    ctx->tune_shade_blocks_per_cu = std::max(1u, env_u32("PTC_SHADE_BLOCKS_PER_CU", ctx->tune_shade_blocks_per_cu));
     ctx->tune_ring = env_u32("PTC_RING", ctx->tune_ring);
     ctx->tune_pass_paths = std::max(1u << 16, std::min(64u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
     *out = ctx.release();

@@ -92,6 +92,7 @@ struct pt_ctx {
     uint32_t tune_variant = 1;           // 0: one batch of rays per wave pass, 1: persistent refill
     uint32_t tune_blocks_per_cu = 6;
     uint32_t tune_refill = 16;
+    uint32_t tune_shade_blocks_per_cu = 64; // k_shade grid cap (blocks loop over the queue beyond it)
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the persistent traversal kernel
     uint32_t tune_pass_paths = 32u << 20; // pt_render: paths in flight per pass (~1.1 KiB of HBM each)
 };

@@ -33,6 +33,7 @@
 #ifndef PTC_SHADE_WAVES
 #define PTC_SHADE_WAVES 4        /* min waves per SIMD asked of the compiler for k_shade */
 #endif
+#define PTC_SHADE_SPAN 2048u     /* queue entries a k_shade block handles per global queue reservation */
 #define PTC_MAX_VERTS 16        /* ArrayVec<_, 16>, scene.rs:324 */
 #define PTC_MAX_ITERS 1024u     /* scene.rs:328 */
 
@@ -95,31 +96,60 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera 
 // ---- shade: one iteration of the loop body scene.rs:333-368 ------------------------------------------
 // The live count is read from the device (st.counts[cin]) so that the host never has to wait for it:
 // the grid is sized for an upper bound and surplus threads only take part in the ballots.
+//
+// The kernel is bound by memory LATENCY (60 % of wave time in s_waitcnt at ~1250 cycles per L2 read),
+// so it is written to keep round trips off the critical path: everything that depends only on the
+// hit (ray, state, shading record, triangle normal) is requested in one batch, the queue slots are
+// reserved (two wave-level atomics) BEFORE the results are stored, and the stores go out last with
+// nothing waiting for them.
 __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState st, uint32_t cur, uint32_t cin,
                                                     uint64_t seed, uint32_t sample_base) {
-    const uint32_t k = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    __shared__ ptc::SpectralLds tab;
+    // ids of the paths this block sends on: survivors fill qbuf from the front, misses from the back
+    // (they are disjoint subsets of the PTC_SHADE_SPAN paths a block handles per span)
+    __shared__ uint32_t qbuf[PTC_SHADE_SPAN];
+    __shared__ uint32_t q_n[2], q_base[2];
     const uint32_t count = st.counts[cin];
     uint32_t* const next_count = &st.counts[cin == 2u ? 0u : cin + 1u];
-    if (k == 0u) st.counts[cin == 0u ? 2u : cin - 1u] = 0u;     // the counter the NEXT iteration fills
-    bool cont = false, missed = false;
-    uint32_t p = 0u;
-    if (k < count) {
-        p = st.queue[cur][k];
-        const uint4 hit = st.hits[p];
-        if (hit.x == PT_NO_TRIANGLE) {
-            // miss: the path ends with {0, sky} (scene.rs:362-367); the sky term is evaluated by k_sky,
-            // once per pass over all such paths, so that this kernel's lanes do not wait for it
-            missed = true;
-        } else {
+    if (blockIdx.x == 0u && threadIdx.x == 0u) st.counts[cin == 0u ? 2u : cin - 1u] = 0u;   // the counter the NEXT iteration fills
+    if (blockIdx.x * PTC_SHADE_SPAN >= count) return;            // surplus block of an over-sized grid
+    ptc::spectral_lds_fill(tab, sc.refl_tab, sc.d65_tab, threadIdx.x, PTC_BLOCK);
+    const uint32_t lane = threadIdx.x & 63u;
+    // grid-stride over the queue in spans of PTC_SHADE_SPAN entries (trip counts are uniform per block)
+    for (uint32_t span0 = blockIdx.x * PTC_SHADE_SPAN; span0 < count; span0 += gridDim.x * PTC_SHADE_SPAN) {
+    if (threadIdx.x < 2u) q_n[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t k0 = span0; k0 < span0 + PTC_SHADE_SPAN && k0 < count; k0 += PTC_BLOCK) {
+        const uint32_t k = k0 + threadIdx.x;
+        const bool active = k < count;
+        const uint32_t p = active ? st.queue[cur][k] : 0u;
+        uint4 hit = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
+        if (active) hit = st.hits[p];
+        // miss: the path ends with {0, sky} (scene.rs:362-367); the sky term is evaluated by k_sky, once
+        // per pass over all such paths, so that this kernel's lanes do not wait for it
+        const bool missed = active && hit.x == PT_NO_TRIANGLE;
+        const bool shading = active && !missed;
+
+        bool cont = false, put_vertex = false, put_dir = false;
+        float weight[PTC_NW], emit[PTC_NW];
+        float4 new_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), new_d = new_o;
+        uint2 new_state = make_uint2(0u, 0u);
+        uint32_t vslot = 0u;
+#pragma unroll
+        for (int i = 0; i < PTC_NW; ++i) { weight[i] = 0.0f; emit[i] = 0.0f; }
+
+        if (shading) {
+            const uint32_t tri = hit.x;
+            // one batch of loads: all of them depend on (p, tri) only
             const float4 ro = st.rays[2u * p], rd = st.rays[2u * p + 1u];
             const uint2 state = st.state[p];
+            const float4* srec = sc.shade + (size_t)tri * 5u;
+            const float4 s0 = srec[0];
+            const float4 t0 = sc.tris[(size_t)tri * 3u];                        // Intersection.normal = tri.n
             uint32_t len = state.y & 0xFFu, iter = state.y >> 8;
             float wl[PTC_NW];
             ptc::wavelengths(rd.w, wl);
-            const uint32_t tri = hit.x;
             const float dist = __uint_as_float(hit.y), hu = __uint_as_float(hit.z), hv = __uint_as_float(hit.w);
-            const float4* srec = sc.shade + (size_t)tri * 5u;
-            const float4 s0 = srec[0];
             const uint32_t mat_id = __float_as_uint(s0.x), flags = __float_as_uint(s0.y);
             const DevMaterial m = sc.materials[mat_id];
             float u = hu, v = hv;
@@ -137,42 +167,42 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
                 ptc::texture_rgb(sc, m.dissolve_img, flat, u, v, dis, g, b);
             }
             const float px = ro.x + rd.x * dist, py = ro.y + rd.y * dist, pz = ro.z + rd.z * dist;   // material.rs:292
+            new_o = make_float4(px, py, pz, __uint_as_float(tri));              // start = Some(triangle), scene.rs:356,360
             if (pt_rng_f32(&rng) >= m.base_dissolve * dis) {                    // material.rs:275
-                // dissolved: pass straight through (scene.rs:357-361)
-                st.rays[2u * p] = make_float4(px, py, pz, __uint_as_float(tri));
-                cont = true;
+                cont = true;                                                    // dissolved: pass straight through (scene.rs:357-361)
             } else {
-                float nx, ny, nz;
+                float nx = t0.x, ny = t0.y, nz = t0.z;
                 if (flags & PT_TRI_HAS_NORMALS) {                               // material.rs:279-282
                     const float4 s2 = srec[2], s3 = srec[3], s4 = srec[4];
                     const float w0 = 1.0f - hu - hv;
                     nx = w0 * s2.x + hu * s2.w + hv * s3.z;
                     ny = w0 * s2.y + hu * s3.x + hv * s3.w;
                     nz = w0 * s2.z + hu * s3.y + hv * s4.x;
-                } else {
-                    const float4 t0 = sc.tris[(size_t)tri * 3u];                // Intersection.normal = tri.n
-                    nx = t0.x; ny = t0.y; nz = t0.z;
                 }
                 if (!(ptc::dot3(nx, ny, nz, rd.x, rd.y, rd.z) < 0.0f)) { nx = -nx; ny = -ny; nz = -nz; }   // :288
                 const float nlen = pt_sqrt(ptc::dot3(nx, ny, nz, nx, ny, nz));  // :290 normalize()
                 nx = nx / nlen; ny = ny / nlen; nz = nz / nlen;
                 float sph[3];
                 pt_rng_unit_sphere(&rng, sph);                                  // material.rs:168
-                const float ndx = nx + sph[0], ndy = ny + sph[1], ndz = nz + sph[2];
+                new_d = make_float4(nx + sph[0], ny + sph[1], nz + sph[2], rd.w);
                 float cr, cg, cb;
                 ptc::texture_rgb(sc, m.diffuse_img, m.diffuse, u, v, cr, cg, cb);
-                float weight[PTC_NW], emit[PTC_NW];
+                // The empty asm makes wavelength i+1 "depend" on the result of wavelength i-1: without it the
+                // compiler puts the table rows of all eight wavelengths in flight at once (64+ VGPRs) and the
+                // kernel drops to two waves per SIMD.  Two wavelengths in flight cover the LDS latency.
 #pragma unroll
-                for (int i = 0; i < PTC_NW; ++i) weight[i] = ptc::reflectance_at_one(sc.refl_tab, cr, cg, cb, wl[i]);
+                for (int i = 0; i < PTC_NW; ++i) {
+                    weight[i] = ptc::reflectance_at_one(tab, cr, cg, cb, wl[i]);
+                    if (i >= 1 && i + 1 < PTC_NW) asm volatile("" : "+v"(wl[i + 1]) : "v"(weight[i - 1]));
+                }
                 if (m.emit_kind == PT_EMIT_ABSORBED_D65) {                      // material.rs:183-185
                     float ar, ag, ab;
                     ptc::texture_rgb(sc, m.absorb_img, m.absorb, u, v, ar, ag, ab);
 #pragma unroll
-                    for (int i = 0; i < PTC_NW; ++i)
-                        emit[i] = ptc::d65_one(sc.d65_tab, wl[i]) * ptc::reflectance_at_one(sc.refl_tab, ar, ag, ab, wl[i]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < PTC_NW; ++i) emit[i] = 0.0f;
+                    for (int i = 0; i < PTC_NW; ++i) {
+                        emit[i] = ptc::d65_one(tab, wl[i]) * ptc::reflectance_at_one(tab, ar, ag, ab, wl[i]);
+                        if (i >= 1 && i + 1 < PTC_NW) asm volatile("" : "+v"(wl[i + 1]) : "v"(emit[i - 1]));
+                    }
                 }
                 bool survive = true;
                 if (len > 1u) {                                                 // scene.rs:342-353
@@ -188,38 +218,55 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
                         for (int i = 0; i < PTC_NW; ++i) weight[i] = 0.0f;
                     }
                 }
-                store_vertex(st, p, len, weight, emit);
+                put_vertex = true;
+                vslot = len;
                 len += 1u;
-                if (survive) {                                                  // scene.rs:354-356
-                    st.rays[2u * p] = make_float4(px, py, pz, __uint_as_float(tri));
-                    st.rays[2u * p + 1u] = make_float4(ndx, ndy, ndz, rd.w);
-                    cont = true;
-                }
+                put_dir = survive;                                              // scene.rs:354-356
+                cont = survive;
             }
             iter += 1u;
             // loop header: `for _ in 0..1024` and the capacity check scene.rs:328-331
             cont = cont && (len < PTC_MAX_VERTS) && (iter < PTC_MAX_ITERS);
-            st.state[p] = make_uint2(rng.index, len | (iter << 8));
+            new_state = make_uint2(rng.index, len | (iter << 8));
+        }
+
+        // hand the path on: ballot -> one LDS atomic per wave and list -> slot in the block's buffer
+        const unsigned long long mmask = __ballot(missed), cmask = __ballot(cont);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (cmask != 0ull) {
+            const int leader = __ffsll((long long)cmask) - 1;
+            uint32_t base = 0u;
+            if ((int)lane == leader) base = atomicAdd(&q_n[0], (uint32_t)__popcll(cmask));
+            base = __shfl(base, leader);
+            if (cont) qbuf[base + (uint32_t)__popcll(cmask & below)] = p;
+        }
+        if (mmask != 0ull) {
+            const int leader = __ffsll((long long)mmask) - 1;
+            uint32_t base = 0u;
+            if ((int)lane == leader) base = atomicAdd(&q_n[1], (uint32_t)__popcll(mmask));
+            base = __shfl(base, leader);
+            if (missed) qbuf[PTC_SHADE_SPAN - 1u - (base + (uint32_t)__popcll(mmask & below))] = p;
+        }
+
+        if (shading) {
+            if (put_vertex) store_vertex(st, p, vslot, weight, emit);
+            if (cont) {
+                st.rays[2u * p] = new_o;
+                if (put_dir) st.rays[2u * p + 1u] = new_d;
+            }
+            st.state[p] = new_state;
         }
     }
-    const uint32_t lane = threadIdx.x & 63u;
-    // misses -> miss queue, survivors -> next queue: ballot -> popcount prefix -> one atomic per wave
-    const unsigned long long mmask = __ballot(missed);
-    if (mmask != 0ull) {
-        const int leader = __ffsll((long long)mmask) - 1;
-        uint32_t base = 0u;
-        if ((int)lane == leader) base = atomicAdd(&st.counts[3], (uint32_t)__popcll(mmask));
-        base = __shfl(base, leader);
-        if (missed) st.miss_queue[base + (uint32_t)__popcll(mmask & ((1ull << lane) - 1ull))] = p;
-    }
-    const unsigned long long mask = __ballot(cont);
-    if (mask != 0ull) {
-        const int leader = __ffsll((long long)mask) - 1;
-        uint32_t base = 0u;
-        if ((int)lane == leader) base = atomicAdd(next_count, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
-        if (cont) st.queue[cur ^ 1u][base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p;
-    }
+    // one global atomic per list and SPAN (a single counter word takes ~90 returning atomics per
+    // microsecond chip-wide: one per wave, as this kernel first did, made those atomics its whole run time)
+    __syncthreads();
+    if (threadIdx.x == 0u && q_n[0] != 0u) q_base[0] = atomicAdd(next_count, q_n[0]);
+    if (threadIdx.x == 64u && q_n[1] != 0u) q_base[1] = atomicAdd(&st.counts[3], q_n[1]);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < q_n[0]; i += PTC_BLOCK) st.queue[cur ^ 1u][q_base[0] + i] = qbuf[i];
+    for (uint32_t i = threadIdx.x; i < q_n[1]; i += PTC_BLOCK) st.miss_queue[q_base[1] + i] = qbuf[PTC_SHADE_SPAN - 1u - i];
+    __syncthreads();
+    }   // spans
 }
 
 // ---- sky: Scene::evaluate_sky for every path of the pass that left the scene (scene.rs:362-367) ------
@@ -358,7 +405,8 @@ extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera
                 rc = ptc_timed_event(ctx, 2 * n_timed + 1);
                 if (rc != PT_OK) return rc;
                 n_timed += 1;
-                hipLaunchKernelGGL(k_shade, dim3((live_ub + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, scene->view,
+                const uint32_t shade_blocks = std::min<uint32_t>((live_ub + PTC_SHADE_SPAN - 1) / PTC_SHADE_SPAN, (uint32_t)ctx->n_cus * ctx->tune_shade_blocks_per_cu);
+                hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(PTC_BLOCK), 0, s, scene->view,
                                    st, enq & 1u, enq % 3u, seed, sample_base);
                 PTC_HIP(ctx, hipMemcpyAsync(&ctx->h_counters[enq % SLOTS], &st.counts[(enq + 1u) % 3u], sizeof(uint32_t),
                                             hipMemcpyDeviceToHost, s));

@@ -65,6 +65,44 @@ __device__ __forceinline__ float d65_one(const float* __restrict__ tab, float wl
     return t0 * (1.0f - alpha) + t1 * alpha;
 }
 
+
+// ---- LDS-resident copies of the two spectral tables (k_shade) ------------------------------------------
+// Rows are padded to float4 and followed by one all-zero row, so that `TABLE.get(i).unwrap_or(0)`
+// (color.rs:48-50, material.rs:139-140) is a clamped index and nothing else; a lane's eight wavelengths
+// then cost 16 ds_read_b128 that never touch the vector-memory address path.
+#define PTC_REFL_ROWS 471u
+#define PTC_D65_ROWS 531u
+struct SpectralLds {
+    float4 refl[PTC_REFL_ROWS + 1u];
+    float d65[PTC_D65_ROWS + 1u];
+};
+__device__ __forceinline__ void spectral_lds_fill(SpectralLds& t, const float* __restrict__ refl_tab,
+                                                  const float* __restrict__ d65_tab, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i <= PTC_REFL_ROWS; i += nthreads)
+        t.refl[i] = (i < PTC_REFL_ROWS) ? make_float4(refl_tab[3u * i], refl_tab[3u * i + 1u], refl_tab[3u * i + 2u], 0.0f)
+                                        : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t i = tid; i <= PTC_D65_ROWS; i += nthreads) t.d65[i] = (i < PTC_D65_ROWS) ? d65_tab[i] : 0.0f;
+}
+__device__ __forceinline__ float reflectance_at_one(const SpectralLds& t, float r, float g, float b, float wl) {
+    const float offset = wl - 360.0f;
+    const float index = pt_floor(offset);
+    const float alpha = offset - index;
+    const uint32_t i = pt_f2usize(index);
+    const float4 b0 = t.refl[i < PTC_REFL_ROWS ? i : PTC_REFL_ROWS];
+    const float4 b1 = t.refl[i < PTC_REFL_ROWS - 1u ? i + 1u : PTC_REFL_ROWS];
+    const float w0 = 1.0f - alpha;
+    return dot3(r, g, b, b0.x * w0 + b1.x * alpha, b0.y * w0 + b1.y * alpha, b0.z * w0 + b1.z * alpha);
+}
+__device__ __forceinline__ float d65_one(const SpectralLds& t, float wl) {
+    const float offset = pt_floor(wl) - 300.0f;
+    const float index = pt_floor(offset);
+    const float alpha = offset - index;
+    const uint32_t i = pt_f2usize(index);
+    const float t0 = t.d65[i < PTC_D65_ROWS ? i : PTC_D65_ROWS];
+    const float t1 = t.d65[i < PTC_D65_ROWS - 1u ? i + 1u : PTC_D65_ROWS];
+    return t0 * (1.0f - alpha) + t1 * alpha;
+}
+
 __device__ __forceinline__ float cmf_lobe(float wl, float weight, float mean, float s1, float s2) {
     const float t = (wl - mean) * (wl < mean ? s1 : s2);
     return weight * pt_expf(-0.5f * (t * t));
