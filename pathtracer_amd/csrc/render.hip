@@ -97,11 +97,10 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera 
 // The live count is read from the device (st.counts[cin]) so that the host never has to wait for it:
 // the grid is sized for an upper bound and surplus threads only take part in the ballots.
 //
-// The kernel is bound by memory LATENCY (60 % of wave time in s_waitcnt at ~1250 cycles per L2 read),
-// so it is written to keep round trips off the critical path: everything that depends only on the
-// hit (ray, state, shading record, triangle normal) is requested in one batch, the queue slots are
-// reserved (two wave-level atomics) BEFORE the results are stored, and the stores go out last with
-// nothing waiting for them.
+// Everything that depends only on the hit (ray, state, shading record, triangle normal) is requested in
+// one batch, the spectral tables live in LDS, and the ids of paths that go on (to the next iteration's
+// queue, or to the miss queue) are collected per block in LDS and appended with ONE global atomic per
+// list and span of PTC_SHADE_SPAN paths.
 __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState st, uint32_t cur, uint32_t cin,
                                                     uint64_t seed, uint32_t sample_base) {
     __shared__ ptc::SpectralLds tab;

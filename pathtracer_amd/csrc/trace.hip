@@ -32,6 +32,9 @@
 #include "../../include/pt_math.h"
 
 #define PTC_BLOCK 256
+#ifndef PTC_TICKET
+#define PTC_TICKET 64u            /* rays a wave reserves per ticket atomic */
+#endif
 
 namespace {
 
@@ -244,10 +247,10 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
         if (!exhausted && (n_idle >= (uint32_t)REFILL || n_idle == 64u)) {
             if (blk_next == blk_end) {
                 uint32_t base = 0u;
-                if (lane == 0u) base = atomicAdd(ticket, 64u);
+                if (lane == 0u) base = atomicAdd(ticket, PTC_TICKET);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= n) { exhausted = true; blk_next = blk_end = 0u; }
-                else { blk_next = base; blk_end = (n - base < 64u) ? n : base + 64u; }
+                else { blk_next = base; blk_end = (n - base < PTC_TICKET) ? n : base + PTC_TICKET; }
             }
             const uint32_t avail = blk_end - blk_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));

@@ -108,3 +108,71 @@ def test_multi_pass_equals_single_pass(oracle, gpu_ctx):
     got = gpu_ctx.render(gpu_ctx.scene(arr), 1024, 1024, 0, 6, 6, seed=4)
     want = oracle.render(oracle.scene(arr), 1024, 1024, 0, 6, 6, seed=4)
     compare_images(got, want, "multi-pass")
+
+
+def _layers(n_layers, z0=-2.0, dz=-0.01, half=4.0, material=1):
+    """n_layers big quads facing the camera, one behind the other (2 triangles each)."""
+    tris = np.zeros(2 * n_layers, dtype=abi.TRIANGLE)
+    for i in range(n_layers):
+        z = z0 + dz * i
+        a, b, c, d = (-half, -half, z), (half, -half, z), (half, half, z), (-half, half, z)
+        for k, (p0, p1, p2) in enumerate(((a, b, c), (a, c, d))):     # quad split as scene.rs:258-261
+            t = tris[2 * i + k]
+            t["a"], t["b"], t["c"] = p0, p1, p2
+            t["material_index"] = material
+    return tris
+
+
+def test_long_dissolve_chains_run_many_iterations(oracle, gpu_ctx):
+    """Mostly-dissolved layers: paths pass through dozens of triangles (scene.rs:357-361), so the path
+    loop runs far more iterations than the host's look-ahead window and its rotating counters."""
+    tris = _layers(120)
+    mats = workloads.soup_materials()
+    mats[1]["base_dissolve"] = 0.06
+    arr = abi.SceneArrays(tris, core.bvh_build(tris), mats, core.sky_d65(1.0))
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 64, 48, 0, 3, 3, seed=7)
+    st = gpu_ctx.stats()
+    want, cnt = oracle.render(oracle.scene(arr), 64, 48, 0, 3, 3, seed=7, count=True)
+    compare_images(got, want, "dissolve chains", max_diff_frac=0.0, mean_rel=0.0)
+    assert st.segments == cnt[1] and st.trace_launches > 40
+    assert st.segments / st.paths > 10
+
+
+def test_iteration_cap_1024(oracle, gpu_ctx):
+    """Fully dissolved layers: every iteration is a pass-through, nothing is ever pushed, and the loop
+    ends at `for _ in 0..1024` (scene.rs:328) with radiance 0 and no sky term."""
+    tris = _layers(1100, dz=-0.004)                    # 1100 triangles along every ray
+    mats = workloads.soup_materials()
+    mats[1]["base_dissolve"] = 0.0
+    arr = abi.SceneArrays(tris, core.bvh_build(tris), mats, core.sky_d65(1.0))
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 16, 16, 0, 1, 1, seed=1)
+    st = gpu_ctx.stats()
+    want, cnt = oracle.render(oracle.scene(arr), 16, 16, 0, 1, 1, seed=1, count=True)
+    assert np.array_equal(got, want)
+    assert (got[..., :3] == 0).all()
+    assert st.segments == cnt[1] == 16 * 16 * 1024
+
+
+def test_sixteen_vertex_cap(oracle, gpu_ctx):
+    """Camera INSIDE a closed box whose reflectance exceeds 1 (Russian roulette's p = max weight is not
+    clamped, scene.rs:343-345, so every path survives): each path stops at exactly 16 scatter vertices
+    (ArrayVec<_,16>, scene.rs:324-331) and no sky term is added."""
+    tris = workloads.box_triangles().copy()
+    for f in ("a", "b", "c"):
+        tris[f][:, 2] += 3.0                        # box centred on the camera: x, y, z in [-1, 1]
+    lid = np.zeros(2, dtype=abi.TRIANGLE)           # close the open side (behind the camera)
+    a, b, c, d = (-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1)
+    for k, (p0, p1, p2) in enumerate(((a, b, c), (a, c, d))):
+        lid[k]["a"], lid[k]["b"], lid[k]["c"] = p0, p1, p2
+        lid[k]["material_index"] = 1
+    mats = workloads.box_materials()
+    for m in mats[1:]:
+        m["diffuse"]["value"] = 2.0
+    arr = abi.SceneArrays(np.concatenate([tris, lid]), None, mats, core.sky_d65(1.0))
+    arr.nodes = core.bvh_build(arr.triangles)
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 48, 48, 0, 4, 4, seed=5)
+    st = gpu_ctx.stats()
+    want, cnt = oracle.render(oracle.scene(arr), 48, 48, 0, 4, 4, seed=5, count=True)
+    compare_images(got, want, "closed box", max_diff_frac=0.0, mean_rel=0.0)
+    assert st.segments == cnt[1] == 16 * st.paths
+    assert np.isfinite(got).all() and got[..., 1].mean() > 0
