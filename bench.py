@@ -124,6 +124,7 @@ def main():
         # warm-up: one full-size pass, so that the pass workspace (about 1.1 KiB per path in flight) is
         # allocated before the timed region
         ctx.render_dev(scene, a.width, a.height, 0, min(a.spectral_spp, 16), spp_total, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
+        sharding.finalize_sums(d_img.clone())       # first use of these torch kernels loads their code objects
         barrier()
         t1 = time.perf_counter()
         buf = sharding.render_sharded(render_sum, spp_total, rank, world, all_reduce if world > 1 else None)
