@@ -55,12 +55,16 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is created even for one rank, so that the
+    # RCCL path of this script can be exercised on a single GPU
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -92,7 +96,7 @@ def main():
         kernel_ms += ctx.stats().trace_ms
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -119,7 +123,7 @@ def main():
             torch.cuda.synchronize()
             reduce_ms[0] = (time.perf_counter() - t1) * 1e3
 
-        if world > 1:   # warm the communicator
+        if use_dist:   # warm the communicator
             dist.all_reduce(torch.zeros(1, device="cuda"))
         # warm-up: one full-size pass, so that the pass workspace (about 1.1 KiB per path in flight) is
         # allocated before the timed region
@@ -127,12 +131,12 @@ def main():
         sharding.finalize_sums(d_img.clone())       # first use of these torch kernels loads their code objects
         barrier()
         t1 = time.perf_counter()
-        buf = sharding.render_sharded(render_sum, spp_total, rank, world, all_reduce if world > 1 else None)
+        buf = sharding.render_sharded(render_sum, spp_total, rank, world, all_reduce if use_dist else None)
         img = sharding.finalize_sums(buf)
         barrier()
         sp_elapsed = time.perf_counter() - t1
         st = ctx.stats()
-        if world > 1:
+        if use_dist:
             t = torch.tensor([sp_elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             sp_elapsed = float(t[0])
@@ -142,7 +146,7 @@ def main():
             "seconds": sp_elapsed, "segments_per_path": st.segments / max(st.paths, 1),
             "trace_Mrays_per_s_rank0": st.trace_rays / max(st.trace_ms, 1e-9) / 1e3,
             "trace_share_of_device_time_rank0": st.trace_ms / max(st.total_ms, 1e-9),
-            "allreduce_ms": reduce_ms[0] if world > 1 else None,
+            "allreduce_ms": reduce_ms[0] if use_dist else None,
             "finite_pixel_fraction": float(torch.isfinite(img[..., 1]).float().mean()),
             "spp_per_rank": a.spectral_spp,
             "config": {"workload": f"soup-{a.tris} + Hosek-Wilkie sky (turbidity 3, albedo 0.3), {a.width}x{a.height}, "
@@ -219,7 +223,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "spectral": spectral,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

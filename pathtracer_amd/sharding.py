@@ -36,8 +36,8 @@ def render_sharded(render_sum, spp_total, rank, world_size, all_reduce=None):
     summed buffer (not yet finalised) on every rank."""
     begin, count = sample_range(spp_total, rank, world_size)
     buf = render_sum(begin, count)
-    if world_size > 1:
-        if all_reduce is None:
-            raise ValueError("all_reduce is required when world_size > 1")
+    if world_size > 1 and all_reduce is None:
+        raise ValueError("all_reduce is required when world_size > 1")
+    if all_reduce is not None:
         all_reduce(buf)
     return buf
