@@ -299,11 +299,11 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const pt_material& m = d->materials[i];
         int rc;
-        if ((rc = check_texture(ctx, m.diffuse, d, 3, "material.diffuse")) != PT_OK) return rc;
-        if ((rc = check_texture(ctx, m.dissolve, d, 1, "material.dissolve")) != PT_OK) return rc;
+        if ((rc = check_texture(ctx, m.diffuse, d, 3, "pt_scene_create: material.diffuse")) != PT_OK) return rc;
+        if ((rc = check_texture(ctx, m.dissolve, d, 1, "pt_scene_create: material.dissolve")) != PT_OK) return rc;
         if (m.emit_kind != PT_EMIT_NULL && m.emit_kind != PT_EMIT_ABSORBED_D65)
             return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: unknown emit kind");
-        if (m.emit_kind == PT_EMIT_ABSORBED_D65 && (rc = check_texture(ctx, m.absorption, d, 3, "material.absorption")) != PT_OK) return rc;
+        if (m.emit_kind == PT_EMIT_ABSORBED_D65 && (rc = check_texture(ctx, m.absorption, d, 3, "pt_scene_create: material.absorption")) != PT_OK) return rc;
         DevMaterial& o = mats[i];
         for (int k = 0; k < 3; ++k) { o.diffuse[k] = m.diffuse.value[k]; o.absorb[k] = m.absorption.value[k]; }
         o.diffuse_img = m.diffuse.kind == PT_TEX_NEAREST ? m.diffuse.image : 0xFFFFFFFFu;

@@ -20,6 +20,15 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    # PyTorch wheels bundle their own HIP/HSA runtime; when libptcore's (/opt/rocm) initialises the
+    # device first, torch's copy later reports "No HIP GPUs".  Tests that hand torch device buffers
+    # to the ABI therefore need torch initialised first (bench.py does the same by construction).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     from pathtracer_amd import core
     ctx = core.Context(0)
     yield ctx

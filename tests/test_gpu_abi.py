@@ -1,0 +1,114 @@
+"""Error behaviour and bookkeeping of the C ABI on a real device (include/ptcore.h): every misuse is an
+error code with text, never an abort; contexts and scenes can be created and destroyed repeatedly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import abi, core, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def test_null_and_invalid_arguments(gpu_ctx):
+    L = core.lib()
+    sc = gpu_ctx.scene(workloads.box_scene())
+    h, s = gpu_ctx.handle, sc.handle
+    rays = core.gen_primary_rays(8, 8)
+    out = np.zeros(64, dtype=abi.HIT)
+    cam = abi.Camera(8, 8, 36.0, 50.0)
+    img = np.zeros((8, 8, 4), dtype=np.float32)
+    assert L.pt_trace_closest(None, s, abi.ptr(rays), None, 64, abi.ptr(out)) == abi.PT_ERR_INVALID
+    assert L.pt_trace_closest(h, None, abi.ptr(rays), None, 64, abi.ptr(out)) == abi.PT_ERR_INVALID
+    assert L.pt_trace_closest(h, s, None, None, 64, abi.ptr(out)) == abi.PT_ERR_INVALID
+    assert L.pt_trace_closest(h, s, abi.ptr(rays), None, 64, None) == abi.PT_ERR_INVALID
+    assert b"NULL" in L.pt_last_error(h)
+    assert L.pt_trace_closest(h, s, None, None, 0, None) == abi.PT_OK          # empty batch needs no buffers
+    assert L.pt_set_traversal(h, 7) == abi.PT_ERR_INVALID
+    assert L.pt_render(h, s, C.byref(cam), 0, 1, 1, 1, 9, abi.ptr(img)) == abi.PT_ERR_INVALID       # unknown mode
+    assert L.pt_render(h, s, C.byref(cam), 0, 1, 0, 1, abi.PT_RENDER_FINAL, abi.ptr(img)) == abi.PT_ERR_INVALID   # spp_total 0
+    assert L.pt_render(h, s, None, 0, 1, 1, 1, 0, abi.ptr(img)) == abi.PT_ERR_INVALID
+    assert L.pt_render(h, s, C.byref(cam), 0xFFFFFFFF, 2, 2, 1, 0, abi.ptr(img)) == abi.PT_ERR_INVALID           # range overflow
+    empty = abi.Camera(0, 8, 36.0, 50.0)
+    assert L.pt_render(h, s, C.byref(empty), 0, 1, 1, 1, 0, abi.ptr(img)) == abi.PT_ERR_INVALID
+    # a zero-sample range is legal: FINAL gives black with alpha 1, SUM gives zeros with w = 0
+    assert L.pt_render(h, s, C.byref(cam), 0, 0, 4, 1, abi.PT_RENDER_FINAL, abi.ptr(img)) == abi.PT_OK
+    assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+    # the context is still usable after errors
+    assert gpu_ctx.trace(sc, rays).size == 64
+
+
+def test_bad_scene_descriptions(gpu_ctx):
+    arr = workloads.box_scene()
+
+    def expect_invalid(mutate):
+        a = abi.SceneArrays(arr.triangles.copy(), arr.nodes.copy(), arr.materials.copy(), arr.sky)
+        mutate(a)
+        with pytest.raises(core.PtError) as e:
+            gpu_ctx.scene(a)
+        assert e.value.code == abi.PT_ERR_INVALID and "pt_scene_create" in str(e.value)
+
+    expect_invalid(lambda a: a.triangles["material_index"].__setitem__(0, 99))
+    expect_invalid(lambda a: a.nodes["shape_index"].__setitem__(np.flatnonzero(a.nodes["is_leaf"])[0], 1000))
+    expect_invalid(lambda a: a.nodes["child_r_index"].__setitem__(0, 10 ** 6))
+    expect_invalid(lambda a: a.materials["emit_kind"].__setitem__(1, 5))
+    expect_invalid(lambda a: a.materials["diffuse"]["kind"].__setitem__(1, abi.PT_TEX_NEAREST))      # image index with no images
+
+    def dup_leaf(a):
+        leaves = np.flatnonzero(a.nodes["is_leaf"])
+        a.nodes["shape_index"][leaves[1]] = a.nodes["shape_index"][leaves[0]]
+    expect_invalid(dup_leaf)
+    bad_sky = core.sky_d65(1.0)
+    bad_sky.kind = 7
+    with pytest.raises(core.PtError):
+        gpu_ctx.scene(abi.SceneArrays(arr.triangles, arr.nodes, arr.materials, bad_sky))
+    with pytest.raises(core.PtError):       # materials[0] is required (scene.rs:204)
+        gpu_ctx.scene(abi.SceneArrays(arr.triangles, arr.nodes, arr.materials[:0], arr.sky))
+
+
+def test_contexts_and_scenes_come_and_go():
+    rays = core.gen_primary_rays(32, 32)
+    ref = None
+    for _ in range(3):
+        ctx = core.Context(0)
+        for n in (50, 500):
+            sc = ctx.scene(workloads.soup_scene(n))
+            hits = ctx.trace(sc, rays)
+            if n == 500:
+                ref = hits if ref is None else ref
+                assert hits.tobytes() == ref.tobytes()
+            sc.close()
+        ctx.close()
+    with pytest.raises(core.PtError):
+        core.Context(4096)                  # device id out of range
+    assert b"out of range" in core.lib().pt_last_error(None)
+
+
+def test_device_pointer_entry_points_match_host_pointer_ones(gpu_ctx):
+    import torch
+    arr = workloads.soup_scene(20_000, sky=workloads.hw_sky())
+    sc = gpu_ctx.scene(arr)
+    rays = core.gen_primary_rays(160, 90)
+    want = gpu_ctx.trace(sc, rays)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
+    d_out = torch.zeros((rays.size, 4), dtype=torch.int32, device="cuda")
+    gpu_ctx.trace_dev(sc, d_rays.data_ptr(), 0, rays.size, d_out.data_ptr())
+    st = gpu_ctx.stats()
+    assert st.trace_rays == rays.size and st.trace_launches == 1 and st.trace_ms > 0
+    assert d_out.cpu().numpy().tobytes() == want.tobytes()
+    img = gpu_ctx.render(sc, 96, 54, 0, 2, 2, seed=3)
+    d_img = torch.zeros((54, 96, 4), dtype=torch.float32, device="cuda")
+    gpu_ctx.render_dev(sc, 96, 54, 0, 2, 2, 3, abi.PT_RENDER_FINAL, d_img.data_ptr())
+    assert d_img.cpu().numpy().tobytes() == img.tobytes()
+    info = sc.info()
+    assert info.n_triangles == 20_000 and info.n_internal_nodes == 19_999 and info.device_bytes > 20_000 * (64 + 48)
+
+
+def test_same_seed_same_image_different_seed_different_image(gpu_ctx):
+    sc = gpu_ctx.scene(workloads.box_scene())
+    a = gpu_ctx.render(sc, 64, 48, 0, 2, 2, seed=11)
+    b = gpu_ctx.render(sc, 64, 48, 0, 2, 2, seed=11)
+    c = gpu_ctx.render(sc, 64, 48, 0, 2, 2, seed=12)
+    d = gpu_ctx.render(sc, 64, 48, 0, 2, 2, seed=11 + (1 << 32))
+    assert a.tobytes() == b.tobytes()
+    assert a.tobytes() != c.tobytes() and a.tobytes() != d.tobytes()
