@@ -201,6 +201,20 @@ int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera* camera, u
                   uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode,
                   float* d_xyzw);
 
+/* ---- after the hot path: the reference's display transform ---------------
+ * What renderer.rs:297-309 + shader.wgsl:32-44 do with the XYZ framebuffer: log-average luminance,
+ * zones (defaults avg_zone 5, white_zone 10: renderer.rs:221-222) -> exposure + extended Reinhard on Y
+ * -> XYZ to linear sRGB.  rgba receives the fragment shader's output (float, alpha passed through),
+ * bgra8 what the Bgra8Unorm surface holds (clamped, quantised, NOT sRGB-encoded: renderer.rs:191);
+ * either may be NULL.  stats_out (nullable) = {avg_luminance, max_luminance, middle_gray}.
+ * PT_TONEMAP_SKIP_NONFINITE (no reference counterpart): NaN/inf pixels are left out of the average
+ * and mapped as black; without it one NaN sample makes the whole display NaN, as in the reference. */
+#define PT_TONEMAP_SKIP_NONFINITE 1u
+int pt_tonemap(pt_ctx* ctx, const float* xyzw, uint32_t width, uint32_t height, float avg_zone,
+               float white_zone, uint32_t flags, float* rgba, uint8_t* bgra8, float stats_out[3]);
+int pt_tonemap_dev(pt_ctx* ctx, const float* d_xyzw, uint32_t width, uint32_t height, float avg_zone,
+                   float white_zone, uint32_t flags, float* d_rgba, uint8_t* d_bgra8, float stats_out[3]);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 typedef struct pt_stats {
     double   trace_ms;        /* HIP-event time of the traversal kernel(s) of the last call        */

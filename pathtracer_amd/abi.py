@@ -27,6 +27,7 @@ PT_TRAVERSE_FAST = 0
 PT_TRAVERSE_EXACT = 1
 PT_RENDER_FINAL = 0
 PT_RENDER_SUM = 1
+PT_TONEMAP_SKIP_NONFINITE = 1
 
 f4, u4 = np.float32, np.uint32
 

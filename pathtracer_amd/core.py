@@ -48,6 +48,8 @@ def lib():
         "pt_set_traversal": (i32, [vp, u32]),
         "pt_render": (i32, [vp, vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp]),
         "pt_render_dev": (i32, [vp, vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp]),
+        "pt_tonemap": (i32, [vp, vp, u32, u32, f32, f32, u32, vp, vp, C.POINTER(f32)]),
+        "pt_tonemap_dev": (i32, [vp, vp, u32, u32, f32, f32, u32, vp, vp, C.POINTER(f32)]),
         "pt_get_stats": (i32, [vp, C.POINTER(abi.Stats)]),
         "pt_scene_get_info": (i32, [vp, C.POINTER(abi.SceneInfo)]),
         "pt_gen_soup": (i32, [u64, u32, C.POINTER(f32), C.POINTER(f32), f32, f32, u32, vp]),
@@ -65,7 +67,7 @@ EXPORTS = [
     "pt_abi_version", "pt_init", "pt_shutdown", "pt_last_error", "pt_bvh_build", "pt_sky_hosek_wilkie",
     "pt_sky_d65", "pt_material_default", "pt_scene_create", "pt_scene_destroy", "pt_trace_closest",
     "pt_trace_closest_dev", "pt_set_traversal", "pt_render", "pt_render_dev", "pt_get_stats",
-    "pt_scene_get_info", "pt_gen_soup", "pt_gen_primary_rays",
+    "pt_scene_get_info", "pt_gen_soup", "pt_gen_primary_rays", "pt_tonemap", "pt_tonemap_dev",
 ]
 
 
@@ -200,6 +202,18 @@ class Context:
         cam = abi.Camera(width, height, sensor_width, focal_length)
         self._check(lib().pt_render_dev(self.handle, scene.handle, C.byref(cam), spp_begin, spp_count, spp_total,
                                         int(seed), int(mode), C.c_void_p(d_out)))
+
+    def tonemap(self, xyzw, avg_zone=5.0, white_zone=10.0, skip_nonfinite=False):
+        """renderer.rs:297-309 + shader.wgsl:32-44: returns (linear-sRGB float RGBA, BGRA8 surface bytes,
+        (avg_luminance, max_luminance, middle_gray))."""
+        xyzw = np.ascontiguousarray(xyzw, dtype=np.float32)
+        h, w = xyzw.shape[0], xyzw.shape[1]
+        rgba = np.zeros((h, w, 4), dtype=np.float32)
+        bgra8 = np.zeros((h, w, 4), dtype=np.uint8)
+        stats = (C.c_float * 3)()
+        self._check(lib().pt_tonemap(self.handle, abi.ptr(xyzw), w, h, float(avg_zone), float(white_zone),
+                                     abi.PT_TONEMAP_SKIP_NONFINITE if skip_nonfinite else 0, abi.ptr(rgba), abi.ptr(bgra8), stats))
+        return rgba, bgra8, tuple(stats)
 
     def stats(self):
         s = abi.Stats()
