@@ -30,9 +30,6 @@
 #include "../../include/pt_rng.h"
 
 #define PTC_BLOCK 256
-#ifndef PTC_SHADE_WAVES
-#define PTC_SHADE_WAVES 4        /* min waves per SIMD asked of the compiler for k_shade */
-#endif
 #define PTC_SHADE_SPAN 2048u     /* queue entries a k_shade block handles per global queue reservation */
 #define PTC_MAX_VERTS 16        /* ArrayVec<_, 16>, scene.rs:324 */
 #define PTC_MAX_ITERS 1024u     /* scene.rs:328 */

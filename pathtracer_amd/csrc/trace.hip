@@ -235,6 +235,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
 
     uint32_t blk_next = 0u, blk_end = 0u;     // wave-uniform: unassigned part of the reserved block
     bool exhausted = false;                    // wave-uniform: the ticket counter ran past n
+    bool first_block = true;                   // wave-uniform
     bool has_ray = false;
     DRay r = {};
     uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE;
@@ -246,9 +247,16 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (!exhausted && (n_idle >= (uint32_t)REFILL || n_idle == 64u)) {
             if (blk_next == blk_end) {
+                // a wave's FIRST block is static (wave id * PTC_TICKET): otherwise every wave of the grid hits
+                // the ticket word at launch, and one word takes only ~90 returning atomics per microsecond
                 uint32_t base = 0u;
-                if (lane == 0u) base = atomicAdd(ticket, PTC_TICKET);
-                base = __builtin_amdgcn_readfirstlane(base);
+                if (first_block) {
+                    base = (gtid >> 6) * PTC_TICKET;
+                    first_block = false;
+                } else {
+                    if (lane == 0u) base = atomicAdd(ticket, PTC_TICKET);
+                    base = __builtin_amdgcn_readfirstlane(base) + (total_threads >> 6) * PTC_TICKET;
+                }
                 if (base >= n) { exhausted = true; blk_next = blk_end = 0u; }
                 else { blk_next = base; blk_end = (n - base < PTC_TICKET) ? n : base + PTC_TICKET; }
             }

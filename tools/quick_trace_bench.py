@@ -58,6 +58,14 @@ for mode, name in ((abi.PT_TRAVERSE_FAST, "fast"), (abi.PT_TRAVERSE_EXACT, "exac
     ms = ms[2:]
     res[name] = d_out.cpu().numpy().copy()
     print(f"{name}: {np.mean(ms):.3f} ms (min {np.min(ms):.3f}) -> {n/np.mean(ms)/1e3:.1f} Mrays/s", flush=True)
+if not a.bounce:
+    ctx.set_traversal(abi.PT_TRAVERSE_FAST)
+    ctx.trace(sc, rays)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.trace(sc, rays)
+    dt = (time.perf_counter() - t0) / 3
+    print(f"host-pointer pt_trace_closest (H2D rays + kernel + D2H hits, pageable numpy buffers): {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} Mrays/s", flush=True)
 import zlib
 print("fast crc", zlib.crc32(res["fast"].tobytes()))
 if not a.fast_only:
