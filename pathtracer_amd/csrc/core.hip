@@ -88,8 +88,8 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
     if ((e = hipHostMalloc((void**)&ctx->h_counters, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
         return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
-    if ((e = hipMalloc((void**)&ctx->ticket, 256)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
-    if ((e = hipMemset(ctx->ticket, 0, 256)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    if ((e = hipMalloc((void**)&ctx->ticket, 4096)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    if ((e = hipMemset(ctx->ticket, 0, 4096)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
     auto env_u32 = [](const char* name, uint32_t def) {
         const char* v = getenv(name);
         return v ? (uint32_t)strtoul(v, nullptr, 10) : def;

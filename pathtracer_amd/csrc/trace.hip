@@ -32,6 +32,9 @@
 #include "../../include/pt_math.h"
 
 #define PTC_BLOCK 256
+#ifndef PTC_SHARDS
+#define PTC_SHARDS 8u             /* ticket words / contiguous ray shards per launch (power of two not required) */
+#endif
 #ifndef PTC_TICKET
 #define PTC_TICKET 64u            /* rays a wave reserves per ticket atomic */
 #endif
@@ -221,9 +224,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
     const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (count_ptr) n = *count_ptr;
-    // two ticket words alternate between launches; this launch clears the one the NEXT launch uses
+    // two sets of ticket words alternate between launches; this launch clears the set the NEXT launch uses
     // (the previous launch, its last user, has completed: launches are stream-ordered)
-    if (gtid == 0u) *ticket_next = 0u;
+    if (gtid < PTC_SHARDS) ticket_next[gtid * 64u] = 0u;
     LaneStack<S> st;
     st.spill = spill + gtid;
     st.spill_stride = total_threads;
@@ -236,6 +239,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
     uint32_t blk_next = 0u, blk_end = 0u;     // wave-uniform: unassigned part of the reserved block
     bool exhausted = false;                    // wave-uniform: the ticket counter ran past n
     bool first_block = true;                   // wave-uniform
+    uint32_t shard = blockIdx.x % PTC_SHARDS, shards_done = 0u;                                // wave-uniform
+    const uint32_t shard_len = ((n + PTC_SHARDS * PTC_TICKET - 1u) / (PTC_SHARDS * PTC_TICKET)) * PTC_TICKET;
+    const uint32_t waves_per_label = (gridDim.x / PTC_SHARDS) * (PTC_BLOCK / 64u);            // grid is a multiple of PTC_SHARDS
     bool has_ray = false;
     DRay r = {};
     uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE;
@@ -246,19 +252,31 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
         const unsigned long long idle = __ballot(!has_ray);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (!exhausted && (n_idle >= (uint32_t)REFILL || n_idle == 64u)) {
-            if (blk_next == blk_end) {
-                // a wave's FIRST block is static (wave id * PTC_TICKET): otherwise every wave of the grid hits
-                // the ticket word at launch, and one word takes only ~90 returning atomics per microsecond
-                uint32_t base = 0u;
+            while (blk_next == blk_end && !exhausted) {
+                // The batch is cut into PTC_SHARDS contiguous shards, each with its own ticket word; a wave
+                // works on the shard of its block label (blockIdx % PTC_SHARDS: blocks with the same label
+                // tend to share an XCD, hence an L2) and moves on to the next shard when its own runs dry.
+                // A wave's FIRST block is static (its rank among the waves of its label): otherwise every
+                // wave of the grid hits a ticket word at launch, and one word takes only ~90 returning
+                // atomics per microsecond.
+                uint32_t off = 0u;
                 if (first_block) {
-                    base = (gtid >> 6) * PTC_TICKET;
+                    off = ((blockIdx.x / PTC_SHARDS) * (PTC_BLOCK / 64u) + (threadIdx.x >> 6)) * PTC_TICKET;
                     first_block = false;
                 } else {
-                    if (lane == 0u) base = atomicAdd(ticket, PTC_TICKET);
-                    base = __builtin_amdgcn_readfirstlane(base) + (total_threads >> 6) * PTC_TICKET;
+                    if (lane == 0u) off = atomicAdd(ticket + shard * 64u, PTC_TICKET);
+                    off = __builtin_amdgcn_readfirstlane(off) + waves_per_label * PTC_TICKET;
                 }
-                if (base >= n) { exhausted = true; blk_next = blk_end = 0u; }
-                else { blk_next = base; blk_end = (n - base < PTC_TICKET) ? n : base + PTC_TICKET; }
+                const uint32_t shard_begin = shard * shard_len;
+                if (off >= shard_len || shard_begin + off >= n) {
+                    shards_done += 1u;
+                    if (shards_done == PTC_SHARDS) { exhausted = true; blk_next = blk_end = 0u; }
+                    else shard = (shard + 1u == PTC_SHARDS) ? 0u : shard + 1u;
+                } else {
+                    const uint32_t shard_end = (n - shard_begin < shard_len) ? n : shard_begin + shard_len;
+                    blk_next = shard_begin + off;
+                    blk_end = (shard_end - blk_next < PTC_TICKET) ? shard_end : blk_next + PTC_TICKET;
+                }
             }
             const uint32_t avail = blk_end - blk_next;
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
@@ -431,6 +449,9 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
     uint32_t max_blocks = (uint32_t)ctx->n_cus * ctx->tune_blocks_per_cu;
     uint32_t blocks = (n + PTC_BLOCK - 1) / PTC_BLOCK;
     if (blocks > max_blocks) blocks = max_blocks;
+    // the persistent kernel's static first blocks assume every block label (blockIdx % PTC_SHARDS) has the
+    // same number of blocks; surplus blocks find nothing to do
+    blocks = (blocks + PTC_SHARDS - 1u) / PTC_SHARDS * PTC_SHARDS;
     const uint32_t total_threads = blocks * PTC_BLOCK;
     // HBM spill columns: depth entries per thread (EXACT needs one frame per tree level too)
     const size_t depth = (size_t)v.max_depth + 2u;
@@ -449,8 +470,8 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
         if (d_queue) PTC_LAUNCH((k_trace_fast<S, true>));
         else PTC_LAUNCH((k_trace_fast<S, false>));
     } else {
-        uint32_t* const ticket = ctx->ticket + 32u * ctx->launch_parity;          // this launch's counter
-        uint32_t* const ticket_next = ctx->ticket + 32u * (ctx->launch_parity ^ 1u);
+        uint32_t* const ticket = ctx->ticket + 512u * ctx->launch_parity;         // this launch's counters (256 B apart)
+        uint32_t* const ticket_next = ctx->ticket + 512u * (ctx->launch_parity ^ 1u);
         ctx->launch_parity ^= 1u;
         const bool q = d_queue != nullptr;
 #define PTC_PERS(SS, R) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, R>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, R>), ticket, ticket_next); } while (0)
