@@ -102,12 +102,20 @@ def test_sample_ranges_compose(oracle, gpu_ctx):
     np.testing.assert_allclose(finalize_sums(a + b), full, rtol=2e-6, atol=1e-9)
 
 
-def test_multi_pass_equals_single_pass(oracle, gpu_ctx):
-    """More samples than fit one pass at this resolution -> several passes; still equal to the oracle."""
-    arr = workloads.box_scene()
-    got = gpu_ctx.render(gpu_ctx.scene(arr), 1024, 1024, 0, 6, 6, seed=4)
-    want = oracle.render(oracle.scene(arr), 1024, 1024, 0, 6, 6, seed=4)
-    compare_images(got, want, "multi-pass")
+def test_multi_pass_equals_single_pass(oracle, monkeypatch):
+    """More samples than fit one pass -> several passes (3 + 3 + 1 samples here, forced with a small
+    PTC_PASS_PATHS on a context of its own); still equal to the oracle bit for bit."""
+    monkeypatch.setenv("PTC_PASS_PATHS", "200000")
+    ctx = core.Context(0)
+    try:
+        arr = workloads.box_scene()
+        got = ctx.render(ctx.scene(arr), 256, 256, 0, 7, 7, seed=4)
+        st = ctx.stats()
+        want, cnt = oracle.render(oracle.scene(arr), 256, 256, 0, 7, 7, seed=4, count=True)
+        compare_images(got, want, "multi-pass", max_diff_frac=0.0, mean_rel=0.0)
+        assert st.paths == 256 * 256 * 7 and st.segments == cnt[1]
+    finally:
+        ctx.close()
 
 
 def _layers(n_layers, z0=-2.0, dz=-0.01, half=4.0, material=1):
