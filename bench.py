@@ -125,9 +125,9 @@ def main():
 
         if use_dist:   # warm the communicator
             dist.all_reduce(torch.zeros(1, device="cuda"))
-        # warm-up: one full-size pass, so that the pass workspace (about 1.1 KiB per path in flight) is
-        # allocated before the timed region
-        ctx.render_dev(scene, a.width, a.height, 0, min(a.spectral_spp, 16), spp_total, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
+        # warm-up: the same call once, so that the pass workspace (about 1.1 KiB per path in flight, sized by
+        # the samples per pass) is allocated before the timed region
+        ctx.render_dev(scene, a.width, a.height, 0, a.spectral_spp, spp_total, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
         sharding.finalize_sums(d_img.clone())       # first use of these torch kernels loads their code objects
         barrier()
         t1 = time.perf_counter()

@@ -99,7 +99,7 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_refill = env_u32("PTC_REFILL", ctx->tune_refill);
     ctx->tune_shade_blocks_per_cu = std::max(1u, env_u32("PTC_SHADE_BLOCKS_PER_CU", ctx->tune_shade_blocks_per_cu));
     ctx->tune_ring = env_u32("PTC_RING", ctx->tune_ring);
-    ctx->tune_pass_paths = std::max(1u << 16, std::min(64u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
+    ctx->tune_pass_paths = std::max(1u << 16, std::min(192u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
     *out = ctx.release();
     return PT_OK;
 }
