@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spectral-spp", type=int, default=64, help="samples per pixel PER RANK of the spectral leg (config 3: 64; 0 = skip)")
-    ap.add_argument("--traversal", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--traversal", choices=["wide", "fast", "exact"], default="wide")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -74,7 +74,7 @@ def main():
     build_s = time.time() - t0
     ctx = core.Context(local_rank)
     scene = ctx.scene(arr)
-    ctx.set_traversal(abi.PT_TRAVERSE_EXACT if a.traversal == "exact" else abi.PT_TRAVERSE_FAST)
+    ctx.set_traversal({"wide": abi.PT_TRAVERSE_WIDE, "fast": abi.PT_TRAVERSE_FAST, "exact": abi.PT_TRAVERSE_EXACT}[a.traversal])
     info = scene.info()
     rays = core.gen_primary_rays(a.width, a.height)
     if world > 1 and rank > 0:
@@ -195,7 +195,7 @@ def main():
             if tj.get("traversal") == a.traversal and tj.get("tris") == a.tris and tj.get("rays") == n:
                 traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         roofline = {
-            "bound": "hbm", "kernel": "k_trace_fast_persistent" if a.traversal == "fast" else "k_trace_exact",
+            "bound": "hbm", "kernel": "k_trace_exact" if a.traversal == "exact" else f"k_trace_fast_persistent ({a.traversal})",
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
             "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_ray": b_ray, "n_node": n_node, "n_tri": n_tri, "visit_counts": counts_src,

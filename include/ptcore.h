@@ -180,11 +180,16 @@ int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
 int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
                          const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out);
 
-/* Traversal flavour used by both calls above. */
-#define PT_TRAVERSE_FAST  0u  /* global-best pruning; same hit as the reference except on exact
-                                 equal-t ties                                          */
+/* Traversal flavour used by both calls above and by pt_render.  All three walk the caller's BVH (same
+ * boxes, same triangles, same arithmetic per box and per triangle) and return the same minimum-t hit. */
+#define PT_TRAVERSE_FAST  0u  /* binary nodes, global-best pruning; same hit as the reference except on
+                                 exact equal-t ties                                    */
 #define PT_TRAVERSE_EXACT 1u  /* replays traverse_recursive's local pruning and tie rules
                                  (bvh.rs:265-306) frame by frame                                   */
+#define PT_TRAVERSE_WIDE  2u  /* two levels of the same tree per step (4 boxes at once, nearest first,
+                                 global-best pruning); as FAST, only an exact equal-t tie can pick
+                                 another triangle                                                  */
+#define PT_TRAVERSE_DEFAULT PT_TRAVERSE_WIDE
 int pt_set_traversal(pt_ctx* ctx, uint32_t mode);
 
 /* ---- seam 3: render (replaces the rayon closure main.rs:58-116) ---------------------------

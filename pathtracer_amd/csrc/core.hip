@@ -122,7 +122,7 @@ extern "C" void pt_shutdown(pt_ctx* ctx) {
 
 extern "C" int pt_set_traversal(pt_ctx* ctx, uint32_t mode) {
     if (!ctx) return PT_ERR_INVALID;
-    if (mode != PT_TRAVERSE_FAST && mode != PT_TRAVERSE_EXACT) return ptc_fail(ctx, PT_ERR_INVALID, "unknown traversal mode");
+    if (mode != PT_TRAVERSE_FAST && mode != PT_TRAVERSE_EXACT && mode != PT_TRAVERSE_WIDE) return ptc_fail(ctx, PT_ERR_INVALID, "unknown traversal mode");
     ctx->traversal = mode;
     return PT_OK;
 }
@@ -254,6 +254,60 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
     }
     if (max_depth > 4096) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_scene_create: BVH deeper than 4096 levels");
 
+    // ---- wide nodes: collapse two binary levels into one record (device_types.h) -----------------------
+    std::vector<float4> wide;
+    uint32_t wide_depth = 0;
+    if (n_internal) {
+        const float inf = pt_inf();
+        struct Job { uint32_t bin, wide, depth; };
+        std::vector<Job> todo;
+        auto new_wide = [&]() { wide.resize(wide.size() + 8u, make_float4(inf, inf, inf, inf)); return (uint32_t)(wide.size() / 8u - 1u); };
+        todo.push_back(Job{0u, new_wide(), 1u});
+        while (!todo.empty()) {
+            const Job j = todo.back();
+            todo.pop_back();
+            if (j.depth > wide_depth) wide_depth = j.depth;
+            struct Child { float lo[3], hi[3]; uint32_t ref; };
+            Child ch[4];
+            int nch = 0;
+            auto box_of = [&](uint32_t bin, int side, Child& c) {
+                const float4* q = &nodes[(size_t)bin * 4u];
+                const float4 lo = q[side ? 2 : 0], hi = q[side ? 3 : 1];
+                c.lo[0] = lo.x; c.lo[1] = lo.y; c.lo[2] = lo.z; c.hi[0] = hi.x; c.hi[1] = hi.y; c.hi[2] = hi.z;
+                uint32_t r; std::memcpy(&r, side ? &q[1].w : &q[0].w, 4);
+                c.ref = r;
+            };
+            for (int side = 0; side < 2; ++side) {
+                Child c; box_of(j.bin, side, c);
+                if (c.ref & PTC_LEAF_BIT) { ch[nch++] = c; continue; }
+                const uint32_t b2 = c.ref;
+                box_of(b2, 0, ch[nch++]);
+                box_of(b2, 1, ch[nch++]);
+            }
+            uint32_t refs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            float4* w = &wide[(size_t)j.wide * 8u];     // (re-taken after every new_wide(): the vector may move)
+            float lo[3][4], hi[3][4];
+            for (int a = 0; a < 3; ++a) for (int k = 0; k < 4; ++k) { lo[a][k] = inf; hi[a][k] = -inf; }
+            // children in reverse so that, popped from `todo`, wide nodes come out in preorder
+            for (int k = nch - 1; k >= 0; --k) {
+                if (ch[k].ref & PTC_LEAF_BIT) { refs[k] = ch[k].ref; continue; }
+                const uint32_t wi = new_wide();
+                refs[k] = wi;
+                todo.push_back(Job{ch[k].ref, wi, j.depth + 1u});
+            }
+            for (int k = 0; k < nch; ++k) for (int a = 0; a < 3; ++a) { lo[a][k] = ch[k].lo[a]; hi[a][k] = ch[k].hi[a]; }
+            w = &wide[(size_t)j.wide * 8u];
+            for (int a = 0; a < 3; ++a) {
+                w[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+                w[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+            }
+            float rb[4];
+            std::memcpy(rb, refs, 16);
+            w[6] = make_float4(rb[0], rb[1], rb[2], rb[3]);
+            w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+
     // ---- Triangle::new (triangle.rs:50-60) ---------------------------------------------------------
     std::vector<float4> tris((size_t)N * 3u), shade((size_t)N * 5u);
     for (uint32_t i = 0; i < N; ++i) {
@@ -343,6 +397,7 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
     int rc;
     const DevSky* d_sky = nullptr;
     if ((rc = upload(ctx, s, nodes, &s->view.nodes, "nodes")) != PT_OK ||
+        (rc = upload(ctx, s, wide, &s->view.wide, "wide nodes")) != PT_OK ||
         (rc = upload(ctx, s, tris, &s->view.tris, "triangles")) != PT_OK ||
         (rc = upload(ctx, s, shade, &s->view.shade, "shading records")) != PT_OK ||
         (rc = upload(ctx, s, mats, &s->view.materials, "materials")) != PT_OK ||
@@ -360,6 +415,7 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
     s->view.n_tris = N;
     s->view.n_materials = d->n_materials;
     s->view.max_depth = max_depth;
+    s->view.wide_depth = wide_depth;
     s->view.root_ref = (N == 1) ? (PTC_LEAF_BIT | d->nodes[0].shape_index) : 0u;
     s->info.n_triangles = N;
     s->info.n_internal_nodes = n_internal;

@@ -23,6 +23,13 @@
 //   q1 = { l.max.x, l.max.y, l.max.z, bits(right ref) }
 //   q2 = { r.min.x, r.min.y, r.min.z, 0 }
 //   q3 = { r.max.x, r.max.y, r.max.z, 0 }
+// ---- wide node (PT_TRAVERSE_WIDE): 128 B = 8 x float4, two levels of the SAME binary tree collapsed:
+// the children of a wide node are the grandchildren of a binary node (a child that is a leaf stays
+// as it is), in the binary order LL, LR, RL, RR, so every box and every triangle reference is the
+// reference builder's; only the order in which boxes are visited can differ from bvh.rs:265-306.
+//   w0..w2 = min.x, min.y, min.z of children 0..3   w3..w5 = max.x, max.y, max.z of children 0..3
+//   w6 = bits(ref 0..3): leaf bit | triangle, or wide-node index, or PTC_IDLE for an empty slot
+//   w7 = unused (keeps the stride one cache line)
 // ---- triangle intersect record: 48 B = 3 x float4 (triangle.rs:17-24)
 //   t0 = { n.xyz, d }   t1 = { n1.xyz, d1 }   t2 = { n2.xyz, d2 }
 // ---- triangle shading record: 80 B = 5 x float4; the common (no uv, no normals) case reads s0 only
@@ -48,6 +55,7 @@ struct DevSky {
 
 struct DevSceneView {       // passed to kernels by value
     const float4* nodes;
+    const float4* wide;         // [n_wide][8], see above
     const float4* tris;
     const float4* shade;
     const DevMaterial* materials;
@@ -58,6 +66,7 @@ struct DevSceneView {       // passed to kernels by value
     const float* solar_tab;     // [11][2][45][4]: the two turbidity rows the scene needs
     const float* limb_tab;      // [11][6]
     uint32_t root_ref;          // PTC_LEAF_BIT|0 for a 1-triangle scene
+    uint32_t wide_depth;        // wide nodes on the longest root-to-leaf path
     uint32_t n_tris;
     uint32_t n_materials;
     uint32_t max_depth;
@@ -78,7 +87,7 @@ struct pt_ctx {
     hipEvent_t count_ev[8] = {};         // pt_render: one per in-flight live-count readback
     std::vector<hipEvent_t> trace_ev;    // pt_render: pairs around every traversal launch (grown on demand)
     uint32_t launch_parity = 0;          // which of the two ticket words the next persistent launch uses
-    uint32_t traversal = PT_TRAVERSE_FAST;
+    uint32_t traversal = PT_TRAVERSE_DEFAULT;
     std::string error;
     pt_stats stats{};
     int n_cus = 0;

@@ -214,7 +214,12 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
 // one at once: each wave reserves blocks of 64 consecutive rays from a global ticket counter (one
 // atomic per 64 rays, fetched by lane 0 and broadcast) and hands them to idle lanes by ballot +
 // popcount rank, whenever at least REFILL lanes are idle.  Lanes only idle during the final drain.
-template <int S, bool QUEUED, int REFILL>
+//
+// WIDE (PT_TRAVERSE_WIDE): the same loop over the two-level records of device_types.h.  A trip tests
+// four boxes (the binary node's grandchildren, same arithmetic per box), sorts the ones worth entering
+// by entry distance, descends into the nearest and pushes the others farthest first.  A ray needs
+// about half as many dependent node fetches, which is what bounds the binary kernel.
+template <int S, bool QUEUED, int REFILL, bool WIDE>
 __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
     DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
@@ -301,17 +306,38 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
         if (has_ray) {
             // ---- phase 1: internal node (bvh.rs:259-325) ----
             if (!(cur & PTC_LEAF_BIT)) {
-                float4 q0, q1, q2, q3;
-                load_node(sc.nodes, cur, q0, q1, q2, q3);
-                float lt, rt;
-                bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);
-                bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);
-                lh = lh && (best_t > lt);
-                rh = rh && (best_t > rt);
-                const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
-                const bool left_first = lt < rt;                              // bvh.rs:266
-                if (lh && rh) st.push(ring, left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
-                cur = (lh && (left_first || !rh)) ? lref : (rh ? rref : PTC_IDLE);
+                if constexpr (WIDE) {
+                    const float4* p = sc.wide + (size_t)cur * 8u;
+                    const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5], rw = p[6];
+                    float k0, k1, k2, k3;
+                    uint32_t r0 = __float_as_uint(rw.x), r1 = __float_as_uint(rw.y), r2 = __float_as_uint(rw.z), r3 = __float_as_uint(rw.w);
+                    const bool h0 = slab(r, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, k0) && r0 != PTC_IDLE && best_t > k0;
+                    const bool h1 = slab(r, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, k1) && r1 != PTC_IDLE && best_t > k1;
+                    const bool h2 = slab(r, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, k2) && r2 != PTC_IDLE && best_t > k2;
+                    const bool h3 = slab(r, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, k3) && r3 != PTC_IDLE && best_t > k3;
+                    k0 = h0 ? k0 : pt_inf(); k1 = h1 ? k1 : pt_inf(); k2 = h2 ? k2 : pt_inf(); k3 = h3 ? k3 : pt_inf();
+                    // 5-exchange sorting network, ascending entry distance (equal keys keep the binary order)
+#define PTC_CSWAP(ka, kb, ra, rb) { const bool sw = ka > kb; const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
+                                    const uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
+                    PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k0, k2, r0, r2) PTC_CSWAP(k1, k3, r1, r3) PTC_CSWAP(k1, k2, r1, r2)
+#undef PTC_CSWAP
+                    if (k3 < pt_inf()) st.push(ring, r3, __float_as_uint(k3));
+                    if (k2 < pt_inf()) st.push(ring, r2, __float_as_uint(k2));
+                    if (k1 < pt_inf()) st.push(ring, r1, __float_as_uint(k1));
+                    cur = (k0 < pt_inf()) ? r0 : PTC_IDLE;
+                } else {
+                    float4 q0, q1, q2, q3;
+                    load_node(sc.nodes, cur, q0, q1, q2, q3);
+                    float lt, rt;
+                    bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);
+                    bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);
+                    lh = lh && (best_t > lt);
+                    rh = rh && (best_t > rt);
+                    const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
+                    const bool left_first = lt < rt;                              // bvh.rs:266
+                    if (lh && rh) st.push(ring, left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
+                    cur = (lh && (left_first || !rh)) ? lref : (rh ? rref : PTC_IDLE);
+                }
             }
             // ---- phase 2: leaf (bvh.rs:327-336) ----
             if ((cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
@@ -454,7 +480,8 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
     blocks = (blocks + PTC_SHARDS - 1u) / PTC_SHARDS * PTC_SHARDS;
     const uint32_t total_threads = blocks * PTC_BLOCK;
     // HBM spill columns: depth entries per thread (EXACT needs one frame per tree level too)
-    const size_t depth = (size_t)v.max_depth + 2u;
+    // (WIDE pushes up to three siblings per level)
+    const size_t depth = ctx->traversal == PT_TRAVERSE_WIDE ? 3u * (size_t)v.wide_depth + 2u : (size_t)v.max_depth + 2u;
     int rc = ptc_reserve(ctx, &ctx->spill, &ctx->spill_bytes, depth * total_threads * sizeof(uint2), "spill");
     if (rc != PT_OK) return rc;
     constexpr int S = 8;
@@ -466,7 +493,7 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
     if (ctx->traversal == PT_TRAVERSE_EXACT) {
         if (d_queue) PTC_LAUNCH((k_trace_exact<S, true>));
         else PTC_LAUNCH((k_trace_exact<S, false>));
-    } else if (ctx->tune_variant == 0) {
+    } else if (ctx->tune_variant == 0 && ctx->traversal != PT_TRAVERSE_WIDE) {
         if (d_queue) PTC_LAUNCH((k_trace_fast<S, true>));
         else PTC_LAUNCH((k_trace_fast<S, false>));
     } else {
@@ -474,15 +501,23 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
         uint32_t* const ticket_next = ctx->ticket + 512u * (ctx->launch_parity ^ 1u);
         ctx->launch_parity ^= 1u;
         const bool q = d_queue != nullptr;
-#define PTC_PERS(SS, R) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, R>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, R>), ticket, ticket_next); } while (0)
-        switch (ctx->tune_ring * 100u + ctx->tune_refill) {
-            case 808:  PTC_PERS(8, 8); break;
-            case 824:  PTC_PERS(8, 24); break;
-            case 832:  PTC_PERS(8, 32); break;
-            case 1016: PTC_PERS(10, 16); break;
-            case 1616: PTC_PERS(16, 16); break;
-            case 816:  PTC_PERS(8, 16); break;
-            default:   PTC_PERS(12, 16); break;
+#define PTC_PERS(SS, R, W) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, R, W>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, R, W>), ticket, ticket_next); } while (0)
+        if (ctx->traversal == PT_TRAVERSE_WIDE) {
+            switch (ctx->tune_ring) {
+                case 8:  PTC_PERS(8, 16, true); break;
+                case 10: PTC_PERS(10, 16, true); break;
+                case 14: PTC_PERS(14, 16, true); break;
+                case 16: PTC_PERS(16, 16, true); break;
+                default: PTC_PERS(12, 16, true); break;
+            }
+        } else switch (ctx->tune_ring * 100u + ctx->tune_refill) {
+            case 808:  PTC_PERS(8, 8, false); break;
+            case 824:  PTC_PERS(8, 24, false); break;
+            case 832:  PTC_PERS(8, 32, false); break;
+            case 1016: PTC_PERS(10, 16, false); break;
+            case 1616: PTC_PERS(16, 16, false); break;
+            case 816:  PTC_PERS(8, 16, false); break;
+            default:   PTC_PERS(12, 16, false); break;
         }
 #undef PTC_PERS
     }

@@ -101,7 +101,7 @@ def test_libm_build_of_the_oracle_bounds_the_pt_math_substitution():
 # ---- GPU: HIP path vs fixtures ----------------------------------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT])
+@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_WIDE])
 def test_gpu_reproduces_hit_fixture(gpu_ctx, soup1m, golden_hits, mode):
     hp, hb, bstart = golden_hits
     sc = gpu_ctx.scene(soup1m)
@@ -110,15 +110,17 @@ def test_gpu_reproduces_hit_fixture(gpu_ctx, soup1m, golden_hits, mode):
     same_hits(gpu_ctx.trace(sc, prim), hp)
     brays, start = fi.bounce_rays(prim, hp)
     same_hits(gpu_ctx.trace(sc, brays, start), hb)
-    gpu_ctx.set_traversal(abi.PT_TRAVERSE_FAST)
+    gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
 
 
 @pytest.mark.gpu
-def test_gpu_full_size_batch_checksum(gpu_ctx, soup1m):
+@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_WIDE])
+def test_gpu_full_size_batch_checksum(gpu_ctx, soup1m, mode):
     """BASELINE configs[1] at full size: all 2 073 600 primary hits, CRC32 against the oracle's."""
     g = json.load(open(os.path.join(G, "soup1m_primary_counts.json")))
     sc = gpu_ctx.scene(soup1m)
     rays = core.gen_primary_rays(1920, 1080)
+    gpu_ctx.set_traversal(mode)
     hits = gpu_ctx.trace(sc, rays)
     assert fi.checksum(hits) == g["hits_checksum"]
     assert abs((hits["tri"] != abi.PT_NO_TRIANGLE).mean() - g["hit_fraction"]) < 1e-12
@@ -128,6 +130,7 @@ def test_gpu_full_size_batch_checksum(gpu_ctx, soup1m):
     # ... and the hit point is on the triangle: barycentrics in [0,1], u+v <= 1, t > 0
     h = hits[hits["tri"] != abi.PT_NO_TRIANGLE]
     assert (h["t"] > 0).all() and (h["u"] >= 0).all() and (h["v"] >= 0).all() and (h["u"] + h["v"] <= 1 + 1e-6).all()
+    gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
 
 
 @pytest.mark.gpu

@@ -47,12 +47,12 @@ def test_box_scene(oracle, gpu_ctx):
     assert st.paths == 96 * 64 * 4 and st.segments >= st.paths
 
 
-@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT])
+@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_WIDE])
 def test_soup_with_hosek_wilkie_sky(oracle, gpu_ctx, mode):
     arr = workloads.soup_scene(20_000, sky=workloads.hw_sky())
     gpu_ctx.set_traversal(mode)
     got = gpu_ctx.render(gpu_ctx.scene(arr), 160, 90, 0, 4, 4, seed=1)
-    gpu_ctx.set_traversal(abi.PT_TRAVERSE_FAST)
+    gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
     want, cnt = oracle.render(oracle.scene(arr), 160, 90, 0, 4, 4, seed=1, count=True)
     assert np.isfinite(want[..., 1]).mean() > 0.5 and np.nanmean(want[..., 1]) > 0
     compare_images(got, want, f"soup+hw mode={mode}")

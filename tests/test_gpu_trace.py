@@ -10,7 +10,7 @@ from pathtracer_amd import abi, core, workloads
 
 pytestmark = pytest.mark.gpu
 
-MODES = [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT]
+MODES = [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_WIDE]
 
 
 def bounce_rays(rng, hits, rays, n):

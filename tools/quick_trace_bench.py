@@ -47,7 +47,7 @@ d_rays = torch.from_numpy(rays.view(np.float32).reshape(n, 8)).cuda()
 d_out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
 res = {}
-for mode, name in ((abi.PT_TRAVERSE_FAST, "fast"), (abi.PT_TRAVERSE_EXACT, "exact")):
+for mode, name in ((abi.PT_TRAVERSE_FAST, "fast"), (abi.PT_TRAVERSE_WIDE, "wide"), (abi.PT_TRAVERSE_EXACT, "exact")):
     if a.fast_only and name == "exact":
         continue
     ctx.set_traversal(mode)
@@ -67,6 +67,6 @@ if not a.bounce:
     dt = (time.perf_counter() - t0) / 3
     print(f"host-pointer pt_trace_closest (H2D rays + kernel + D2H hits, pageable numpy buffers): {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} Mrays/s", flush=True)
 import zlib
-print("fast crc", zlib.crc32(res["fast"].tobytes()))
+print("fast crc", zlib.crc32(res["fast"].tobytes()), "wide crc", zlib.crc32(res["wide"].tobytes()))
 if not a.fast_only:
     print("fast==exact ids:", np.array_equal(res["fast"][:, 0], res["exact"][:, 0]), "all:", np.array_equal(res["fast"], res["exact"]))
