@@ -26,7 +26,7 @@ PASSES=(
 )
 for pass in "${PASSES[@]}"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  timeout -s KILL 300 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -o $TAG -- python3 $R/bench.py $ARGS --spectral-spp 0 > $OUT/pmc_$name.log 2>&1 || { echo "pmc pass $pass failed"; tail -3 $OUT/pmc_$name.log; }
+  timeout -s KILL 300 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -o $TAG -- python3 $R/bench.py $ARGS --spectral-spp 0 > $OUT/pmc_$name.log 2>&1 || { echo "pmc pass $pass failed"; tail -3 $OUT/pmc_$name.log; exit 1; }
 done
 python3 $R/tools/summarize_prof.py $OUT $TAG > $OUT/summary_$TAG.txt 2>&1
 cat $OUT/summary_$TAG.txt
