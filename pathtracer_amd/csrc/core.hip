@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 
@@ -258,7 +259,7 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
     std::vector<float4> wide;
     uint32_t wide_depth = 0;
     if (n_internal) {
-        const float inf = pt_inf();
+        const float inf = pt_inf(), nan = std::numeric_limits<float>::quiet_NaN();
         struct Job { uint32_t bin, wide, depth; };
         std::vector<Job> todo;
         auto new_wide = [&]() { wide.resize(wide.size() + 8u, make_float4(inf, inf, inf, inf)); return (uint32_t)(wide.size() / 8u - 1u); };
@@ -287,7 +288,8 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
             uint32_t refs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             float4* w = &wide[(size_t)j.wide * 8u];     // (re-taken after every new_wide(): the vector may move)
             float lo[3][4], hi[3][4];
-            for (int a = 0; a < 3; ++a) for (int k = 0; k < 4; ++k) { lo[a][k] = inf; hi[a][k] = -inf; }
+            // unused slots: a NaN box fails intersects_aabb for every ray (tmax stays NaN, `tmax >= tmin` is false)
+            for (int a = 0; a < 3; ++a) for (int k = 0; k < 4; ++k) { lo[a][k] = nan; hi[a][k] = nan; }
             // children in reverse so that, popped from `todo`, wide nodes come out in preorder
             for (int k = nch - 1; k >= 0; --k) {
                 if (ch[k].ref & PTC_LEAF_BIT) { refs[k] = ch[k].ref; continue; }

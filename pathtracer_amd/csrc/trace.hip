@@ -68,6 +68,30 @@ __device__ __forceinline__ bool slab(const DRay& r, float bx0, float by0, float 
     return tmax >= tmin;
 }
 
+// The same test split for the 4-box records: slab_axis2 does one axis of two boxes (packed f32
+// subtract and multiply: one rounding per half, as in `slab`), slab_close the min/max chain of one box.
+typedef float ptc_f2 __attribute__((ext_vector_type(2)));
+struct PairF { ptc_f2 t1, t2; };
+__device__ __forceinline__ PairF slab_axis2(float lo_a, float lo_b, float hi_a, float hi_b, float o, float inv) {
+    const ptc_f2 lo = {lo_a, lo_b}, hi = {hi_a, hi_b}, oo = {o, o}, ii = {inv, inv};
+    PairF p;
+    p.t1 = (lo - oo) * ii;
+    p.t2 = (hi - oo) * ii;
+    return p;
+}
+__device__ __forceinline__ bool slab_close(float t1x, float t2x, float t1y, float t2y, float t1z, float t2z,
+                                           float& tmin_out) {
+    float tmin = pt_fmin(t1x, t2x);
+    float tmax = pt_fmax(t1x, t2x);
+    tmin = pt_fmax(tmin, pt_fmin(t1y, t2y));
+    tmax = pt_fmin(tmax, pt_fmax(t1y, t2y));
+    tmin = pt_fmax(tmin, pt_fmin(t1z, t2z));
+    tmax = pt_fmin(tmax, pt_fmax(t1z, t2z));
+    tmin = pt_fmax(tmin, 0.0f);
+    tmin_out = tmin;
+    return tmax >= tmin;
+}
+
 // Triangle::intersect with max_distance = INFINITY (bvh.rs:332), branch-free until the verdict
 __device__ __forceinline__ bool tri_test(const DRay& r, float4 t0, float4 t1, float4 t2,
                                          float& dist, float& uo, float& vo) {
@@ -98,36 +122,46 @@ __device__ __forceinline__ bool tri_test(const DRay& r, float4 t0, float4 t1, fl
 // [depth][thread] in HBM.  LDS and HBM accesses are kept in separate, differently-flavoured
 // branches on purpose: if both sides were plain loads the compiler would select between the two
 // ADDRESSES and emit one flat_load, which is far slower than ds_read_b64.
+__device__ __forceinline__ uint32_t ptc_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
 template <int S>
 struct LaneStack {
     uint2* spill;        // &column[0][gtid]; depth stride = spill_stride
     uint32_t spill_stride;
-    uint32_t sp;         // logical size
-    uint32_t base;       // entries [0, base) live in HBM, [base, sp) in LDS
+    uint32_t idx;        // element index of the next free ring slot: slot * PTC_BLOCK + threadIdx.x
+    uint32_t cnt;        // entries in LDS (the newest `cnt` of the stack)
+    uint32_t base;       // entries below them, in HBM
 
-    __device__ __forceinline__ void reset() { sp = 0u; base = 0u; }
+    __device__ __forceinline__ void reset() { idx = threadIdx.x; cnt = 0u; base = 0u; }
+    __device__ __forceinline__ bool empty() const { return (cnt | base) == 0u; }
     __device__ __forceinline__ void push(uint2* __restrict__ ring, uint32_t a, uint32_t b) {
-        if (__builtin_expect(sp - base == (uint32_t)S, 0)) {
-            const uint2 old = ring[(base % S) * PTC_BLOCK + threadIdx.x];
+        if (__builtin_expect(cnt == (uint32_t)S, 0)) {      // ring full: the next free slot holds the oldest entry
+            const uint2 old = ring[idx];
             __builtin_nontemporal_store(old.x, &spill[(size_t)base * spill_stride].x);
             __builtin_nontemporal_store(old.y, &spill[(size_t)base * spill_stride].y);
             base += 1u;
+            cnt -= 1u;
         }
-        ring[(sp % S) * PTC_BLOCK + threadIdx.x] = make_uint2(a, b);
-        sp += 1u;
+        ring[idx] = make_uint2(a, b);
+        idx += PTC_BLOCK;
+        idx = ptc_umin(idx, idx - (uint32_t)(S * PTC_BLOCK));      // wraps: idx - S*BLOCK underflows unless idx >= S*BLOCK
+        cnt += 1u;
     }
-    __device__ __forceinline__ uint2 pop(const uint2* __restrict__ ring) {     // caller checks sp > 0
-        sp -= 1u;
+    __device__ __forceinline__ uint2 pop(const uint2* __restrict__ ring) {     // caller checks !empty()
         // the LDS read is unconditional (its slot always exists) so that it stays a ds_read_b64;
         // the rare HBM refill overrides it
-        uint2 e = ring[(sp % S) * PTC_BLOCK + threadIdx.x];
-        if (__builtin_expect(sp < base, 0)) {
-            base = sp;
+        const uint32_t prev = ptc_umin(idx - PTC_BLOCK, idx + (uint32_t)((S - 1) * PTC_BLOCK));
+        uint2 e = ring[prev];
+        if (__builtin_expect(cnt == 0u, 0)) {
+            base -= 1u;
             // volatile: keeps this a separate global load (otherwise LLVM selects between the LDS
             // and HBM ADDRESSES and emits one slow flat_load for every pop)
-            const volatile uint32_t* col = reinterpret_cast<const volatile uint32_t*>(&spill[(size_t)sp * spill_stride]);
+            const volatile uint32_t* col = reinterpret_cast<const volatile uint32_t*>(&spill[(size_t)base * spill_stride]);
             e.x = col[0];
             e.y = col[1];
+        } else {
+            cnt -= 1u;
+            idx = prev;
         }
         return e;
     }
@@ -198,7 +232,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
             }
             // ---- phase 3: pop until something is still worth entering ----
             while (cur == PTC_IDLE) {
-                if (st.sp == 0u) { alive = false; break; }
+                if (st.empty()) { alive = false; break; }
                 const uint2 e = st.pop(ring);
                 if (best_t > __uint_as_float(e.y)) cur = e.x;
             }
@@ -311,10 +345,15 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                     const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5], rw = p[6];
                     float k0, k1, k2, k3;
                     uint32_t r0 = __float_as_uint(rw.x), r1 = __float_as_uint(rw.y), r2 = __float_as_uint(rw.z), r3 = __float_as_uint(rw.w);
-                    const bool h0 = slab(r, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, k0) && r0 != PTC_IDLE && best_t > k0;
-                    const bool h1 = slab(r, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, k1) && r1 != PTC_IDLE && best_t > k1;
-                    const bool h2 = slab(r, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, k2) && r2 != PTC_IDLE && best_t > k2;
-                    const bool h3 = slab(r, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, k3) && r3 != PTC_IDLE && best_t > k3;
+                    // the 24 subtractions and 24 products of the four slab tests, two boxes per packed
+                    // instruction (v_pk_add_f32 / v_pk_mul_f32 round each half like the scalar forms)
+                    const PairF ax = slab_axis2(lox.x, lox.y, hix.x, hix.y, r.ox, r.ix), bx = slab_axis2(lox.z, lox.w, hix.z, hix.w, r.ox, r.ix);
+                    const PairF ay = slab_axis2(loy.x, loy.y, hiy.x, hiy.y, r.oy, r.iy), by = slab_axis2(loy.z, loy.w, hiy.z, hiy.w, r.oy, r.iy);
+                    const PairF az = slab_axis2(loz.x, loz.y, hiz.x, hiz.y, r.oz, r.iz), bz = slab_axis2(loz.z, loz.w, hiz.z, hiz.w, r.oz, r.iz);
+                    const bool h0 = slab_close(ax.t1.x, ax.t2.x, ay.t1.x, ay.t2.x, az.t1.x, az.t2.x, k0) && best_t > k0;
+                    const bool h1 = slab_close(ax.t1.y, ax.t2.y, ay.t1.y, ay.t2.y, az.t1.y, az.t2.y, k1) && best_t > k1;
+                    const bool h2 = slab_close(bx.t1.x, bx.t2.x, by.t1.x, by.t2.x, bz.t1.x, bz.t2.x, k2) && best_t > k2;
+                    const bool h3 = slab_close(bx.t1.y, bx.t2.y, by.t1.y, by.t2.y, bz.t1.y, bz.t2.y, k3) && best_t > k3;
                     k0 = h0 ? k0 : pt_inf(); k1 = h1 ? k1 : pt_inf(); k2 = h2 ? k2 : pt_inf(); k3 = h3 ? k3 : pt_inf();
                     // 5-exchange sorting network, ascending entry distance (equal keys keep the binary order)
 #define PTC_CSWAP(ka, kb, ra, rb) { const bool sw = ka > kb; const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
@@ -353,7 +392,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
             }
             // ---- phase 3: pop; an empty stack ends the ray ----
             while (cur == PTC_IDLE) {
-                if (st.sp == 0u) {
+                if (st.empty()) {
                     out[ray_i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
                                             __float_as_uint(best_u), __float_as_uint(best_v));
                     has_ray = false;
@@ -427,7 +466,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, cons
                     }
                 }
             } else {
-                if (st.sp == 0u) { alive = false; break; }
+                if (st.empty()) { alive = false; break; }
                 const uint2 e = st.pop(ring);
                 const bool is_b = ((e.x & PTC_FRAME_BIT) != 0u) && ((e.x & PTC_LEAF_BIT) == 0u);
                 if (!is_b) {
