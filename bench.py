@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--spectral-spp", type=int, default=64, help="samples per pixel PER RANK of the spectral leg (config 3: 64; 0 = skip)")
     ap.add_argument("--traversal", choices=["wide", "fast", "exact"], default="wide")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --one-device rehearses the N>1 code path on a 1-GPU box")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     a = ap.parse_args()
 
     import torch
@@ -54,6 +56,8 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if a.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run (RANK set) the process group is created even for one rank, so that the
     # RCCL path of this script can be exercised on a single GPU
@@ -61,7 +65,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     def barrier():
         if use_dist:
@@ -150,7 +157,7 @@ def main():
             "finite_pixel_fraction": float(torch.isfinite(img[..., 1]).float().mean()),
             "spp_per_rank": a.spectral_spp,
             "config": {"workload": f"soup-{a.tris} + Hosek-Wilkie sky (turbidity 3, albedo 0.3), {a.width}x{a.height}, "
-                                   f"{spp_total} spp, seed 1 (BASELINE configs[2] at N=1)"},
+                                   f"{spp_total} spp, seed 1 (BASELINE configs[2]: 64 spp per GPU, samples split across ranks)"},
         }
 
     # ---- CPU baseline + visit counts (rank 0, N = 1 only: bounded, about 10-30 s of CPU work) -------
@@ -202,7 +209,7 @@ def main():
             "kernel_ms": kernel_ms_avg,
             "algorithmic_bytes_per_launch": b_ray * n,
             "note": "achieved = algorithmic bytes (B_ray = 32 + 16 + 64*n_node + 48*n_tri under the REFERENCE's traversal "
-                    "rule, SURVEY.md 8d) / kernel time. The 112 MB node+triangle set is re-read from L1/L2/Infinity Cache, "
+                    "rule, SURVEY.md 8d) / kernel time. The ~100 MB node+triangle set is re-read from L1/L2/Infinity Cache, "
                     "so measured HBM-side traffic is a small fraction of the algorithmic bytes and the kernel is bound by "
                     "the vector-memory address path and VALU issue, not by HBM (DESIGN.md)",
         }
