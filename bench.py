@@ -182,6 +182,21 @@ def main():
                           f"(recursive traversal, bvh.rs:250-338), {o.nthreads} threads",
                 "id_mismatches_vs_gpu": int((got != want["tri"]).sum()),
             }
+            if spectral is not None:
+                # spectral leg beside it: sample 0 of every pixel (1 of the 64 spp: ~2 M paths, ~8 M segments)
+                t1 = time.perf_counter()
+                cpu_img = o.render(osc, a.width, a.height, 0, 1, spp_total, 1, mode=abi.PT_RENDER_SUM)
+                cpu_s = time.perf_counter() - t1
+                ctx.render_dev(scene, a.width, a.height, 0, 1, spp_total, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
+                gpu_img = d_img.cpu().numpy()
+                cpu_img = cpu_img.reshape(gpu_img.shape)
+                same = ((gpu_img.view(np.uint32) == cpu_img.view(np.uint32)) | (np.isnan(gpu_img) & np.isnan(cpu_img))).all(axis=-1)
+                spectral["cpu_baseline"] = {
+                    "value": 1.0 / cpu_s, "unit": "spp/s", "cores": o.nthreads, "kind": "port",
+                    "sample": f"sample 0 of every pixel of the {a.width}x{a.height} frame (1 spp of {spp_total}), {cpu_s:.1f} s, "
+                              f"reference-algorithm CPU restatement, {o.nthreads} threads",
+                    "pixels_differing_vs_gpu": int((~same).sum()),
+                }
         except Exception as e:  # oracle not built: keep the bench usable, say so
             cpu_baseline = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
     if n_node is None and os.path.exists(golden):
