@@ -165,6 +165,24 @@ void pt_sky_d65(float power, pt_sky* out);
 /* Material::default() (material.rs:300-309). */
 void pt_material_default(pt_material* out);
 
+/* ---- before the hot path: scene ingestion ------------------------------------
+ * Scene::load (scene.rs:194-282) on the host: the TOML scene file (scene.rs:64-183, serde defaults
+ * included), its OBJ/MTL meshes (mesh.transform * camera_transform, quads split (a,b,c),(a,c,d),
+ * Material::from_mtl material.rs:206-253) and PNG textures, then BVH::build.  Does not touch the GPU.
+ * The arrays in `desc` are owned by the pt_scene_file and stay valid until pt_scene_file_free; hand
+ * `desc` to pt_scene_create as it is.  Errors (the reference's Err returns and panics): PT_ERR_INVALID
+ * with the text in pt_last_error(NULL). */
+typedef struct pt_scene_file pt_scene_file;
+typedef struct pt_scene_file_info {
+    pt_scene_desc desc;
+    pt_camera camera;              /* scene::Camera resolution, sensor_width, focal_length (scene.rs:134-152) */
+    uint32_t samples;              /* scene::Camera.samples                                                   */
+    float camera_transform[16];    /* column-major, as Matrix4::from([[f32;4];4])                             */
+} pt_scene_file_info;
+int  pt_scene_file_load(const char* toml_path, pt_scene_file** out);
+int  pt_scene_file_get(const pt_scene_file* file, pt_scene_file_info* out);
+void pt_scene_file_free(pt_scene_file* file);
+
 /* ---- seam 1: scene upload (replaces holding Scene{bvh,triangles,materials,sky}, scene.rs:273-281)
  * Copies the caller's arrays, flattens nodes to the 64-byte device layout and triangles to the
  * 48-byte intersect record + shading record, and owns the device memory until destroy. */

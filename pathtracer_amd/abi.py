@@ -75,6 +75,10 @@ class SceneDesc(C.Structure):
                 ("sky", Sky)]
 
 
+class SceneFileInfo(C.Structure):
+    _fields_ = [("desc", SceneDesc), ("camera", Camera), ("samples", C.c_uint32), ("camera_transform", C.c_float * 16)]
+
+
 class Stats(C.Structure):
     _fields_ = [("trace_ms", C.c_double), ("trace_rays", C.c_uint64), ("trace_launches", C.c_uint32),
                 ("total_ms", C.c_double), ("paths", C.c_uint64), ("segments", C.c_uint64)]

@@ -54,6 +54,9 @@ def lib():
         "pt_scene_get_info": (i32, [vp, C.POINTER(abi.SceneInfo)]),
         "pt_gen_soup": (i32, [u64, u32, C.POINTER(f32), C.POINTER(f32), f32, f32, u32, vp]),
         "pt_gen_primary_rays": (i32, [C.POINTER(abi.Camera), vp]),
+        "pt_scene_file_load": (i32, [C.c_char_p, C.POINTER(vp)]),
+        "pt_scene_file_get": (i32, [vp, C.POINTER(abi.SceneFileInfo)]),
+        "pt_scene_file_free": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -68,6 +71,7 @@ EXPORTS = [
     "pt_sky_d65", "pt_material_default", "pt_scene_create", "pt_scene_destroy", "pt_trace_closest",
     "pt_trace_closest_dev", "pt_set_traversal", "pt_render", "pt_render_dev", "pt_get_stats",
     "pt_scene_get_info", "pt_gen_soup", "pt_gen_primary_rays", "pt_tonemap", "pt_tonemap_dev",
+    "pt_scene_file_load", "pt_scene_file_get", "pt_scene_file_free",
 ]
 
 
@@ -123,6 +127,47 @@ def gen_primary_rays(width, height, sensor_width=36.0, focal_length=50.0):
     if rc != abi.PT_OK:
         raise PtError(rc, "pt_gen_primary_rays failed")
     return out
+
+
+class LoadedScene:
+    """What Scene::load returns (scene.rs:273-281), as the arrays the C ABI takes."""
+
+    def __init__(self, arrays, camera, camera_transform):
+        self.arrays, self.camera, self.camera_transform = arrays, camera, camera_transform
+
+
+def load_scene_file(path):
+    """Scene::load through the library's C++ loader (pt_scene_file_load): TOML + OBJ/MTL + PNG -> arrays.
+    Raises ValueError where the reference returns an error or panics."""
+    h = C.c_void_p()
+    rc = lib().pt_scene_file_load(os.fsencode(str(path)), C.byref(h))
+    if rc != abi.PT_OK:
+        raise ValueError((lib().pt_last_error(None) or b"").decode())
+    try:
+        info = abi.SceneFileInfo()
+        lib().pt_scene_file_get(h, C.byref(info))
+        d = info.desc
+
+        def copy(ptr, n, dtype):
+            if n == 0:
+                return np.zeros(0, dtype=dtype)
+            return np.frombuffer(C.string_at(ptr, n * np.dtype(dtype).itemsize), dtype=dtype).copy()
+
+        tris = copy(d.triangles, d.n_triangles, abi.TRIANGLE)
+        nodes = copy(d.nodes, d.n_nodes, abi.BVH_NODE) if d.n_nodes else None
+        mats = copy(d.materials, d.n_materials, abi.MATERIAL)
+        images = []
+        for k in range(d.n_images):
+            im = d.images[k]
+            tex = copy(im.texels, im.width * im.height * im.channels, np.float32)
+            images.append(tex.reshape((im.height, im.width, 3) if im.channels == 3 else (im.height, im.width)))
+        sky = abi.Sky.from_buffer_copy(bytes(d.sky))
+        cam = {"resolution": (info.camera.width, info.camera.height), "sensor_width": info.camera.sensor_width,
+               "focal_length": info.camera.focal_length, "samples": info.samples}
+        m = np.array(list(info.camera_transform), dtype=np.float32).reshape(4, 4).T.copy()      # m[row, col]
+        return LoadedScene(abi.SceneArrays(tris, nodes, mats, sky, images), cam, m)
+    finally:
+        lib().pt_scene_file_free(h)
 
 
 # ---- device side ------------------------------------------------------------------------------

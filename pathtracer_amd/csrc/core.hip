@@ -16,6 +16,7 @@
 #include <limits>
 #include <memory>
 #include <mutex>
+#include <new>
 
 #include "device_types.h"
 #include "tables.h"
@@ -75,22 +76,25 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
         return ptc_fail(nullptr, PT_ERR_HIP, std::string("pt_init: no HIP device: ") + hipGetErrorString(e));
     int dev = device_ids ? device_ids[0] : 0;
     if (dev < 0 || dev >= count) return ptc_fail(nullptr, PT_ERR_INVALID, "pt_init: device id out of range");
-    auto ctx = std::make_unique<pt_ctx>();
+    // a half-built context is torn down by pt_shutdown (every member starts out null)
+    struct Guard { pt_ctx* p; ~Guard() { if (p) pt_shutdown(p); } } guard{new (std::nothrow) pt_ctx()};
+    if (!guard.p) return ptc_fail(nullptr, PT_ERR_NOMEM, "pt_init: out of host memory");
+    pt_ctx* ctx = guard.p;
     ctx->device = dev;
-    if ((e = hipSetDevice(dev)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    auto bad = [&](const char* what) { return ptc_fail(nullptr, e == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP,
+                                                       std::string("pt_init: ") + what + ": " + hipGetErrorString(e)); };
+    if ((e = hipSetDevice(dev)) != hipSuccess) return bad("hipSetDevice");
     hipDeviceProp_t prop;
-    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return bad("hipGetDeviceProperties");
     ctx->n_cus = prop.multiProcessorCount;
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
-        return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate");
     for (auto& ev : ctx->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bad("hipEventCreate");
     for (auto& ev : ctx->count_ev)
-        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
-    if ((e = hipHostMalloc((void**)&ctx->h_counters, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess)
-        return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
-    if ((e = hipMalloc((void**)&ctx->ticket, 4096)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
-    if ((e = hipMemset(ctx->ticket, 0, 4096)) != hipSuccess) return ptc_fail(nullptr, PT_ERR_HIP, hipGetErrorString(e));
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate");
+    if ((e = hipHostMalloc((void**)&ctx->h_counters, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bad("hipHostMalloc");
+    if ((e = hipMalloc((void**)&ctx->ticket, 4096)) != hipSuccess) return bad("hipMalloc");
+    if ((e = hipMemset(ctx->ticket, 0, 4096)) != hipSuccess) return bad("hipMemset");
     auto env_u32 = [](const char* name, uint32_t def) {
         const char* v = getenv(name);
         return v ? (uint32_t)strtoul(v, nullptr, 10) : def;
@@ -101,7 +105,8 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_shade_blocks_per_cu = std::max(1u, env_u32("PTC_SHADE_BLOCKS_PER_CU", ctx->tune_shade_blocks_per_cu));
     ctx->tune_ring = env_u32("PTC_RING", ctx->tune_ring);
     ctx->tune_pass_paths = std::max(1u << 16, std::min(192u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
-    *out = ctx.release();
+    guard.p = nullptr;
+    *out = ctx;
     return PT_OK;
 }
 
@@ -227,18 +232,19 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
         // depth = internal nodes on the longest root-to-leaf path (bounds the traversal stack)
         std::vector<uint32_t> depth(n_nodes, 0u);
         if (n_nodes) depth[0] = d->nodes[0].is_leaf ? 0u : 1u;
-        std::vector<uint8_t> seen(N, 0);
+        std::vector<uint8_t> seen(N, 0), reached(n_nodes, 0);
         for (uint32_t i = 0; i < n_nodes; ++i) {
             const pt_bvh_node& nd = d->nodes[i];
+            if (i != 0 && !reached[i]) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: node unreachable from the root");
             if (nd.is_leaf) {
                 if (seen[nd.shape_index]) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: triangle referenced by two leaves");
                 seen[nd.shape_index] = 1;
                 continue;
             }
-            if (depth[i] == 0 && i != 0) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: node unreachable from the root");
             if (depth[i] > max_depth) max_depth = depth[i];
             auto ref_of = [&](uint32_t child) -> uint32_t {
                 const pt_bvh_node& c = d->nodes[child];
+                reached[child] = 1;
                 if (c.is_leaf) { depth[child] = depth[i]; return PTC_LEAF_BIT | c.shape_index; }
                 depth[child] = depth[i] + 1;
                 return internal_rank[child];

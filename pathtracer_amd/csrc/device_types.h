@@ -28,7 +28,7 @@
 // as it is), in the binary order LL, LR, RL, RR, so every box and every triangle reference is the
 // reference builder's; only the order in which boxes are visited can differ from bvh.rs:265-306.
 //   w0..w2 = min.x, min.y, min.z of children 0..3   w3..w5 = max.x, max.y, max.z of children 0..3
-//   w6 = bits(ref 0..3): leaf bit | triangle, or wide-node index, or PTC_IDLE for an empty slot
+//   w6 = bits(ref 0..3): leaf bit | triangle, or wide-node index; an empty slot holds a NaN box (never hit)
 //   w7 = unused (keeps the stride one cache line)
 // ---- triangle intersect record: 48 B = 3 x float4 (triangle.rs:17-24)
 //   t0 = { n.xyz, d }   t1 = { n1.xyz, d1 }   t2 = { n2.xyz, d2 }

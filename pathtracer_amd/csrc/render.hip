@@ -329,9 +329,21 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
+static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
+                       uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* d_xyzw);
+
 extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
                              uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* d_xyzw) {
     if (!ctx) return PT_ERR_INVALID;
+    const int rc = render_impl(ctx, scene, cam, spp_begin, spp_count, spp_total, seed, mode, d_xyzw);
+    // an error can leave kernels of the aborted render queued: drain them so that the workspace and the
+    // events are quiet before the caller's next call (the error text is kept)
+    if (rc != PT_OK && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
+                       uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* d_xyzw) {
     if (!scene || !cam || !d_xyzw) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: NULL argument");
     if (cam->width == 0 || cam->height == 0) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: empty image");
     if (mode != PT_RENDER_FINAL && mode != PT_RENDER_SUM) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: unknown mode");

@@ -141,3 +141,12 @@ def test_bad_scene_is_an_error_code(gpu_ctx):
     bad2 = abi.SceneArrays(arr.triangles, arr.nodes[:-1], arr.materials, arr.sky)
     with pytest.raises(core.PtError):
         gpu_ctx.scene(bad2)
+    # a child referenced by two parents leaves another node (here a leaf) unreachable
+    bad3 = abi.SceneArrays(arr.triangles, arr.nodes.copy(), arr.materials, arr.sky)
+    internal = np.flatnonzero(bad3.nodes["is_leaf"] == 0)
+    leaf_parent = next(i for i in internal[::-1] if bad3.nodes["is_leaf"][bad3.nodes["child_l_index"][i]]
+                       and bad3.nodes["is_leaf"][bad3.nodes["child_r_index"][i]])
+    bad3.nodes["child_l_index"][leaf_parent] = bad3.nodes["child_r_index"][leaf_parent]
+    with pytest.raises(core.PtError) as e:
+        gpu_ctx.scene(bad3)
+    assert e.value.code == abi.PT_ERR_INVALID and "pt_scene_create" in str(e.value)

@@ -189,6 +189,105 @@ def test_png_reader_filters(tmp_path):
     assert not has_alpha and np.array_equal(got, px)
 
 
+# ---- the library's C++ loader (pt_scene_file_load) against the Python restatement of the same rules ----
+
+def same_loaded_scene(a, b):
+    assert a.camera == b.camera
+    assert a.camera_transform.tobytes() == b.camera_transform.tobytes()
+    assert a.arrays.triangles.tobytes() == b.arrays.triangles.tobytes()
+    assert (a.arrays.nodes is None) == (b.arrays.nodes is None)
+    if a.arrays.nodes is not None:
+        assert a.arrays.nodes.tobytes() == b.arrays.nodes.tobytes()
+    assert a.arrays.materials.tobytes() == b.arrays.materials.tobytes()
+    assert bytes(a.arrays.sky) == bytes(b.arrays.sky)
+    assert len(a.arrays.images) == len(b.arrays.images)
+    for x, y in zip(a.arrays.images, b.arrays.images):
+        assert x.shape == y.shape
+        np.testing.assert_allclose(x, y, rtol=3e-7, atol=0)      # powf of two libms: 1-2 ulp
+
+
+SCENES = {
+    "empty": "",
+    "basic": '[camera]\nresolution = [64, 48]\nsamples = 4\n[sky]\npower = 1.0\n[[meshes]]\npath = "m.obj"\n',
+    "matrices": '[camera]\ntransform = [[1,0,0,0],[0,1,0,0],[0,0,1,0],[0,0,-5,1]]\n[[meshes]]\npath = "m.obj"\n'
+                'transform = [[2,0,0,0],[0,2,0,0],[0,0,2,0],[0,0,0,1]]\n',
+    "look_at_hw": '# a comment\n[camera]\nsensor_width = 24.0 # trailing\nfocal_length = 35\n'
+                  'transform = { eye = [0.5, 1.25, 5], target = [0, 0.1, 0], up = [0, 1, 0] }\n'
+                  '[sky]\natmospheric_turbidity = 3.0\nground_albedo = 0.3\nzenith_direction = [0, 1, 0]\n'
+                  'sun_direction = [\n  0.3,\n  0.8, # inside an array\n  0.5,\n]\n'
+                  '[[meshes]]\npath = "m.obj"\n[[meshes]]\npath = \'m.obj\'\ntransform = [[1,0,0,0],[0,1,0,0],[0,0,1,0],[0.25,0,-1,1]]\n',
+    "dotted_table": '[camera.transform]\neye = [0, 0, 5]\ntarget = [0, 0, 0]\nup = [0, 1, 0]\n[camera]\nsamples = 1_000\n',
+}
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_cpp_loader_agrees_with_the_python_restatement(scene_dir, name):
+    from pathtracer_amd import core
+    (scene_dir / "s.toml").write_text(SCENES[name])
+    same_loaded_scene(core.load_scene_file(scene_dir / "s.toml"), scene_io.load_scene(scene_dir / "s.toml"))
+
+
+def test_cpp_loader_errors(scene_dir):
+    from pathtracer_amd import core
+    (scene_dir / "five.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nf 1 2 3 4 5\n")
+    (scene_dir / "part.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nvt 0 0\nf 1/1 2 3\n")
+    cases = {
+        '[[meshes]]\npath = "five.obj"\n': "5-gon",
+        '[[meshes]]\npath = "part.obj"\n': "texture coords",
+        '[[meshes]]\npath = "nosuch.obj"\n': "cannot open",
+        '[[meshes]]\n': "path",
+        '[sky]\natmospheric_turbidity = 3.0\nground_albedo = 0.3\nzenith_direction = [0,1,0]\nsun_direction = [0,-1,0]\n': "elevation",
+        '[sky]\n': "sky",
+        '[camera]\nresolution = [64]\n': "resolution",
+        '[camera]\nsamples = "many"\n': "samples",
+        '[camera\n': "TOML line 1",
+        'a = 1\na = 2\n': "duplicate",
+    }
+    for text, needle in cases.items():
+        (scene_dir / "e.toml").write_text(text)
+        with pytest.raises(ValueError, match=needle):
+            core.load_scene_file(scene_dir / "e.toml")
+    with pytest.raises(ValueError, match="cannot open"):
+        core.load_scene_file(scene_dir / "absent.toml")
+
+
+def test_cpp_png_reader(tmp_path):
+    """The library's own inflate + PNG defilter: dynamic-Huffman, fixed-Huffman and stored streams, palette + tRNS."""
+    from pathtracer_amd import core
+    rng = np.random.default_rng(5)
+    smooth = (np.add.outer(np.arange(40), np.arange(56))[..., None] * np.array([1, 2, 3]) % 256).astype(np.uint8)
+    noisy = rng.integers(0, 256, size=(9, 7, 4), dtype=np.uint8)
+    grey_alpha = rng.integers(0, 256, size=(5, 5, 2), dtype=np.uint8)
+
+    def write(name, px, level):
+        h, w, c = px.shape
+        ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+        raw = b"".join(b"\x00" + px[y].tobytes() for y in range(h))
+
+        def chunk(tag, data):
+            return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+        comp = zlib.compress(raw, level)
+        (tmp_path / name).write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+                                      + chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b""))
+
+    # palette image with a tRNS chunk (colour type 3)
+    idx = rng.integers(0, 4, size=(6, 5, 1), dtype=np.uint8)
+    raw = b"".join(b"\x00" + idx[y].tobytes() for y in range(6))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    (tmp_path / "pal.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 5, 6, 8, 3, 0, 0, 0))
+                                       + chunk(b"PLTE", bytes([255, 0, 0, 0, 255, 0, 0, 0, 255, 90, 90, 90]))
+                                       + chunk(b"tRNS", bytes([0, 128])) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    write("smooth.png", smooth, 9)        # dynamic Huffman with long matches
+    write("noisy.png", noisy, 0)          # stored blocks
+    write("ga.png", grey_alpha, 1)
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 -1\nv 1 0 -1\nv 0 1 -1\nusemtl a\nf 1 2 3\nusemtl b\nf 1 2 3\nusemtl c\nf 1 2 3\nusemtl d\nf 1 2 3\n")
+    (tmp_path / "m.mtl").write_text("newmtl a\nmap_Kd smooth.png\nmap_d smooth.png\nnewmtl b\nmap_Ka noisy.png\nmap_d noisy.png\nnewmtl c\nmap_Kd ga.png\nmap_d ga.png\nnewmtl d\nmap_Kd pal.png\nmap_d pal.png\n")
+    (tmp_path / "s.toml").write_text('[[meshes]]\npath = "m.obj"\n')
+    same_loaded_scene(core.load_scene_file(tmp_path / "s.toml"), scene_io.load_scene(tmp_path / "s.toml"))
+
+
 @pytest.mark.gpu
 def test_loaded_scene_renders_like_the_oracle(oracle, gpu_ctx, scene_dir):
     (scene_dir / "s.toml").write_text('[camera]\nresolution = [64, 48]\nsamples = 4\n[sky]\npower = 1.0\n[[meshes]]\npath = "m.obj"\n')
