@@ -219,7 +219,11 @@ private:
         }
         return out;
     }
+    int depth_ = 0;
+    struct Nest { int& d; explicit Nest(int& x) : d(x) { ++d; } ~Nest() { --d; } };
     Value value() {
+        Nest nest(depth_);
+        if (depth_ > 64) err("arrays / inline tables nested deeper than 64 levels");
         Value v;
         const char c = peek();
         if (c == '"' || c == '\'') { v.kind = Value::String; v.s = string(); return v; }
@@ -422,7 +426,7 @@ private:
         return need < 32 ? v & ((1u << need) - 1u) : v;
     }
     static void build(Huff& h, const uint8_t* len, int n) {
-        memset(h.count, 0, sizeof(h.count));
+        memset(&h, 0, sizeof(h));
         for (int i = 0; i < n; ++i) h.count[len[i]]++;
         h.count[0] = 0;
         uint16_t offs[16];

@@ -1,10 +1,18 @@
 #!/bin/bash
 # Host-only AddressSanitizer + UBSan run of the CPU oracle and of the library's host-side code
-# (BVH build, sky cooking, generators).  GPU sanitizers are not available on this pool.
+# (BVH build, sky cooking, generators, scene-file loader incl. its TOML / OBJ / PNG parsers on mutated inputs).  GPU sanitizers are not available on this pool.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); D=${PT_SAN_DIR:-/tmp/asan}; mkdir -p $D
 make -s -C $R/oracle tables.o && make -s -C $R/pathtracer_amd/csrc tables.o
 F="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=undefined -shared -pthread"
 g++ $F $R/oracle/pt_oracle.cpp $R/oracle/tables.o -o $D/libptoracle.so
-g++ $F $R/pathtracer_amd/csrc/host_bvh.cpp $R/pathtracer_amd/csrc/host_sky.cpp $R/pathtracer_amd/csrc/host_gen.cpp $R/pathtracer_amd/csrc/tables.o -o $D/libpthost.so
-LD_PRELOAD="$(gcc -print-file-name=libasan.so) $LD_PRELOAD" ASAN_OPTIONS=detect_leaks=0 PT_SAN_DIR=$D python3 $R/tools/sanitize_host_run.py
+cat > $D/stub.cpp <<'EOS'
+// stand-ins for the two error helpers that live in core.hip (GPU side, not part of this build)
+#include <string>
+struct pt_ctx;
+static std::string g_err;
+int ptc_fail(pt_ctx*, int code, const std::string& msg) { g_err = msg; return code; }
+extern "C" const char* pt_last_error(const pt_ctx*) { return g_err.c_str(); }
+EOS
+g++ $F $R/pathtracer_amd/csrc/host_bvh.cpp $R/pathtracer_amd/csrc/host_sky.cpp $R/pathtracer_amd/csrc/host_gen.cpp $R/pathtracer_amd/csrc/host_scene_io.cpp $D/stub.cpp $R/pathtracer_amd/csrc/tables.o -o $D/libpthost.so
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so) $LD_PRELOAD" ASAN_OPTIONS=detect_leaks=0 PT_SAN_DIR=$D python3 $R/tools/sanitize_host_run.py

@@ -32,4 +32,48 @@ for n in (1,2,7,5000,60000):
         O.pto_render(h,C.byref(cam),0,2,2,1,0,abi.ptr(img),c4,4)
         O.pto_scene_destroy(h)
     print("n",n,"ok hits",(out["tri"]!=0xFFFFFFFF).mean(),"segments",c4[1])
+
+# ---- scene-file loader: a valid scene, then seeded byte mutations of each input file (must fail cleanly or load) ----
+import struct, tempfile, zlib
+H.pt_scene_file_load.argtypes=[C.c_char_p,C.POINTER(vp)]; H.pt_scene_file_free.argtypes=[vp]
+H.pt_scene_file_get.argtypes=[vp,C.POINTER(abi.SceneFileInfo)]
+H.pt_last_error.restype=C.c_char_p; H.pt_last_error.argtypes=[vp]
+def png(px):
+    h,w,c=px.shape; ct={1:0,2:4,3:2,4:6}[c]
+    raw=b"".join(bytes([y%5])+px[y].tobytes() for y in range(h))      # every filter type (content is then arbitrary)
+    ch=lambda t,d: struct.pack(">I",len(d))+t+d+struct.pack(">I",zlib.crc32(t+d)&0xFFFFFFFF)
+    return b"\x89PNG\r\n\x1a\n"+ch(b"IHDR",struct.pack(">IIBBBBB",w,h,8,ct,0,0,0))+ch(b"IDAT",zlib.compress(raw,9))+ch(b"IEND",b"")
+rng=np.random.default_rng(7)
+files={
+ "s.toml": b'[camera]\nresolution = [64, 48]\nsamples = 4\ntransform = { eye = [0, 0, 5], target = [0, 0, 0], up = [0, 1, 0] }\n'
+           b'[sky]\natmospheric_turbidity = 3.0\nground_albedo = 0.3\nzenith_direction = [0, 1, 0]\nsun_direction = [0.3, 0.8, 0.5]\n'
+           b'[[meshes]]\npath = "m.obj"\ntransform = [[1,0,0,0],[0,1,0,0],[0,0,1,0],[0,0,-1,1]]\n',
+ "m.obj": b"mtllib m.mtl\nv -1 -1 -3\nv 1 -1 -3\nv 1 1 -3\nv -1 1 -3\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\nusemtl a\nf 1/1/1 2/2/1 3/3/1 4/4/1\nusemtl b\nf -4 -3 -2\n",
+ "m.mtl": b"newmtl a\nKd 0.8 0.1 0.1\nd 0.5\nmap_Kd t.png\nmap_d t.png\nnewmtl b\nKe 1 1 1\nmap_Ka t.png\n",
+ "t.png": png(rng.integers(0,256,size=(16,16,4),dtype=np.uint8)),
+}
+with tempfile.TemporaryDirectory() as d:
+    def write(over=None):
+        for k,v in files.items(): open(os.path.join(d,k),"wb").write(over.get(k,v) if over else v)
+    def load():
+        h=vp(); rc=H.pt_scene_file_load(os.path.join(d,"s.toml").encode(),C.byref(h))
+        if rc==0:
+            info=abi.SceneFileInfo(); H.pt_scene_file_get(h,C.byref(info)); n=info.desc.n_triangles; H.pt_scene_file_free(h); return n
+        assert rc in (1,3) and H.pt_last_error(None)
+        return None
+    write(); assert load()==3
+    ok=bad=0
+    for name in files:
+        for it in range(400):
+            b=bytearray(files[name]); k=int(rng.integers(1,4))
+            for _ in range(k):
+                op=int(rng.integers(0,3)); pos=int(rng.integers(0,len(b)))
+                if op==0: b[pos]=int(rng.integers(0,256))
+                elif op==1: del b[pos:pos+int(rng.integers(1,8))]
+                else: b[pos:pos]=bytes(rng.integers(0,256,size=int(rng.integers(1,6)),dtype=np.uint8))
+            write({name:bytes(b)})
+            if load() is None: bad+=1
+            else: ok+=1
+    write({"s.toml": b"a = "+b"["*5000+b"]"*5000+b"\n"}); assert load() is None      # nesting limit, no stack overflow
+    print("loader mutations:",ok,"loaded,",bad,"rejected cleanly")
 print("sanitizer run clean")
