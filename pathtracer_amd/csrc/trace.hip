@@ -247,18 +247,18 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
 // slowest lane keeps only ~1/3 of its lanes busy.  Here a lane that finishes its ray takes the next
 // one at once: each wave reserves blocks of 64 consecutive rays from a global ticket counter (one
 // atomic per 64 rays, fetched by lane 0 and broadcast) and hands them to idle lanes by ballot +
-// popcount rank, whenever at least REFILL lanes are idle.  Lanes only idle during the final drain.
+// popcount rank, whenever at least `refill` lanes are idle.  Lanes only idle during the final drain.
 //
 // WIDE (PT_TRAVERSE_WIDE): the same loop over the two-level records of device_types.h.  A trip tests
 // four boxes (the binary node's grandchildren, same arithmetic per box), sorts the ones worth entering
 // by entry distance, descends into the nearest and pushes the others farthest first.  A ray needs
 // about half as many dependent node fetches, which is what bounds the binary kernel.
-template <int S, bool QUEUED, int REFILL, bool WIDE>
+template <int S, bool QUEUED, bool WIDE>
 __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
     DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
     uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket,
-    uint32_t* __restrict__ ticket_next) {
+    uint32_t* __restrict__ ticket_next, uint32_t refill) {
     __shared__ uint2 ring[S * PTC_BLOCK];
     const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
         // ---- refill ----
         const unsigned long long idle = __ballot(!has_ray);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (!exhausted && (n_idle >= (uint32_t)REFILL || n_idle == 64u)) {
+        if (!exhausted && (n_idle >= refill || n_idle == 64u)) {
             while (blk_next == blk_end && !exhausted) {
                 // The batch is cut into PTC_SHARDS contiguous shards, each with its own ticket word; a wave
                 // works on the shard of its block label (blockIdx % PTC_SHARDS: blocks with the same label
@@ -540,23 +540,21 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
         uint32_t* const ticket_next = ctx->ticket + 512u * (ctx->launch_parity ^ 1u);
         ctx->launch_parity ^= 1u;
         const bool q = d_queue != nullptr;
-#define PTC_PERS(SS, R, W) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, R, W>), ticket, ticket_next); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, R, W>), ticket, ticket_next); } while (0)
+#define PTC_PERS(SS, W) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, W>), ticket, ticket_next, refill); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, W>), ticket, ticket_next, refill); } while (0)
+        const uint32_t refill = ctx->tune_refill < 1u ? 1u : (ctx->tune_refill > 64u ? 64u : ctx->tune_refill);
         if (ctx->traversal == PT_TRAVERSE_WIDE) {
             switch (ctx->tune_ring) {
-                case 8:  PTC_PERS(8, 16, true); break;
-                case 10: PTC_PERS(10, 16, true); break;
-                case 14: PTC_PERS(14, 16, true); break;
-                case 16: PTC_PERS(16, 16, true); break;
-                default: PTC_PERS(12, 16, true); break;
+                case 8:  PTC_PERS(8, true); break;
+                case 10: PTC_PERS(10, true); break;
+                case 14: PTC_PERS(14, true); break;
+                case 16: PTC_PERS(16, true); break;
+                default: PTC_PERS(12, true); break;
             }
-        } else switch (ctx->tune_ring * 100u + ctx->tune_refill) {
-            case 808:  PTC_PERS(8, 8, false); break;
-            case 824:  PTC_PERS(8, 24, false); break;
-            case 832:  PTC_PERS(8, 32, false); break;
-            case 1016: PTC_PERS(10, 16, false); break;
-            case 1616: PTC_PERS(16, 16, false); break;
-            case 816:  PTC_PERS(8, 16, false); break;
-            default:   PTC_PERS(12, 16, false); break;
+        } else switch (ctx->tune_ring) {
+            case 8:  PTC_PERS(8, false); break;
+            case 10: PTC_PERS(10, false); break;
+            case 16: PTC_PERS(16, false); break;
+            default: PTC_PERS(12, false); break;
         }
 #undef PTC_PERS
     }
