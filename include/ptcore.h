@@ -187,6 +187,14 @@ void pt_scene_file_free(pt_scene_file* file);
  * Copies the caller's arrays, flattens nodes to the 64-byte device layout and triangles to the
  * 48-byte intersect record + shading record, and owns the device memory until destroy. */
 int  pt_scene_create(pt_ctx* ctx, const pt_scene_desc* desc, pt_scene** out);
+/* Same, with the BVH built ON THE GPU instead of taken from the caller (no counterpart
+ * in the reference, whose BVH::build is a host recursion): desc->nodes must be NULL.  LBVH — 63-bit Morton
+ * order of the triangle boxes' centres, Karras radix tree, boxes fitted bottom-up — so the TOPOLOGY differs
+ * from BVH::build: every pt_trace_closest / pt_render result is still the minimum-t hit over the same
+ * triangles with the same arithmetic, only exact equal-t ties can resolve differently, and traversal visits
+ * more nodes than in the SAH tree.  pt_get_stats().total_ms afterwards = device time of the build. */
+#define PT_SCENE_BUILD_LBVH 1u
+int  pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* desc, uint32_t flags, pt_scene** out);
 void pt_scene_destroy(pt_ctx* ctx, pt_scene* scene);
 
 /* ---- seam 2: closest hit (replaces self.bvh.traverse(&ray, start, &self.triangles), scene.rs:333)

@@ -131,6 +131,19 @@ public:
         d.sky = sky.sky;
         dev.check(pt_scene_create(dev.handle(), &d, &scene_));
     }
+    // the same scene with the BVH built on the GPU (LBVH, pt_scene_create_ex; no counterpart in the reference)
+    static Scene with_device_bvh(Device& dev, const std::vector<Triangle>& triangles, const std::vector<Material>& materials,
+                                 const Sky& sky, const std::vector<pt_image>& images = {}, const Camera& cam = Camera()) {
+        Scene s(dev);
+        s.camera = cam;
+        pt_scene_desc d{};
+        d.triangles = triangles.data(); d.n_triangles = (uint32_t)triangles.size();
+        d.materials = materials.data(); d.n_materials = (uint32_t)materials.size();
+        d.images = images.data(); d.n_images = (uint32_t)images.size();
+        d.sky = sky.sky;
+        dev.check(pt_scene_create_ex(dev.handle(), &d, PT_SCENE_BUILD_LBVH, &s.scene_));
+        return s;
+    }
     // Scene::load (scene.rs:194-282): TOML scene file + OBJ/MTL + PNG, BVH::build, upload
     static Scene load(Device& dev, const std::string& path) {
         pt_scene_file* f = nullptr;

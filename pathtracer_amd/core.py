@@ -42,6 +42,7 @@ def lib():
         "pt_sky_d65": (None, [f32, C.POINTER(abi.Sky)]),
         "pt_material_default": (None, [vp]),
         "pt_scene_create": (i32, [vp, C.POINTER(abi.SceneDesc), C.POINTER(vp)]),
+        "pt_scene_create_ex": (i32, [vp, C.POINTER(abi.SceneDesc), u32, C.POINTER(vp)]),
         "pt_scene_destroy": (None, [vp, vp]),
         "pt_trace_closest": (i32, [vp, vp, vp, vp, u32, vp]),
         "pt_trace_closest_dev": (i32, [vp, vp, vp, vp, u32, vp]),
@@ -71,7 +72,7 @@ EXPORTS = [
     "pt_sky_d65", "pt_material_default", "pt_scene_create", "pt_scene_destroy", "pt_trace_closest",
     "pt_trace_closest_dev", "pt_set_traversal", "pt_render", "pt_render_dev", "pt_get_stats",
     "pt_scene_get_info", "pt_gen_soup", "pt_gen_primary_rays", "pt_tonemap", "pt_tonemap_dev",
-    "pt_scene_file_load", "pt_scene_file_get", "pt_scene_file_free",
+    "pt_scene_file_load", "pt_scene_file_get", "pt_scene_file_free", "pt_scene_create_ex",
 ]
 
 
@@ -213,10 +214,15 @@ class Context:
             lib().pt_shutdown(self.handle)
             self.handle = None
 
-    def scene(self, arrays):
+    def scene(self, arrays, lbvh=False):
+        """pt_scene_create; lbvh=True builds the BVH on the GPU instead (pt_scene_create_ex, arrays.nodes is ignored)."""
         d = arrays.desc()
         h = C.c_void_p()
-        self._check(lib().pt_scene_create(self.handle, C.byref(d), C.byref(h)))
+        if lbvh:
+            d.nodes, d.n_nodes = None, 0
+            self._check(lib().pt_scene_create_ex(self.handle, C.byref(d), abi.PT_SCENE_BUILD_LBVH, C.byref(h)))
+        else:
+            self._check(lib().pt_scene_create(self.handle, C.byref(d), C.byref(h)))
         return Scene(self, h, arrays)
 
     def set_traversal(self, mode):

@@ -191,15 +191,22 @@ extern "C" void pt_scene_destroy(pt_ctx* ctx, pt_scene* scene) {
 }
 
 extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** out) {
+    return pt_scene_create_ex(ctx, d, 0u, out);
+}
+
+extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t flags, pt_scene** out) {
     if (!ctx) return PT_ERR_INVALID;
     if (!d || !out) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: NULL argument");
     *out = nullptr;
+    if (flags & ~PT_SCENE_BUILD_LBVH) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create_ex: unknown flag");
+    const bool lbvh = (flags & PT_SCENE_BUILD_LBVH) != 0u;
+    if (lbvh && (d->nodes || d->n_nodes)) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create_ex: PT_SCENE_BUILD_LBVH takes no nodes");
     const uint32_t N = d->n_triangles;
     if (N >= PTC_INDEX_MASK) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_scene_create: more than 2^30-2 triangles");
     if (N && !d->triangles) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: triangles is NULL");
     if (d->n_materials == 0 || !d->materials)
         return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: materials[0] (Material::default) is required");
-    if (N == 0 ? d->n_nodes != 0 : d->n_nodes != 2 * N - 1)
+    if (!lbvh && (N == 0 ? d->n_nodes != 0 : d->n_nodes != 2 * N - 1))
         return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: n_nodes must be 2*n_triangles-1 (BVH::build, one triangle per leaf)");
     if (d->n_nodes && !d->nodes) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: nodes is NULL");
     if (d->sky.kind != PT_SKY_D65 && d->sky.kind != PT_SKY_HOSEK_WILKIE)
@@ -224,7 +231,7 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
             internal_rank[i] = n_internal++;
         }
     }
-    if (N && n_internal != N - 1) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: expected n_triangles-1 internal nodes");
+    if (!lbvh && N && n_internal != N - 1) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: expected n_triangles-1 internal nodes");
 
     std::vector<float4> nodes((size_t)n_internal * 4u);
     uint32_t max_depth = 0;
@@ -317,9 +324,18 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
     }
 
     // ---- Triangle::new (triangle.rs:50-60) ---------------------------------------------------------
-    std::vector<float4> tris((size_t)N * 3u), shade((size_t)N * 5u);
+    std::vector<float4> tris((size_t)N * 3u), shade((size_t)N * 5u), boxes(lbvh ? (size_t)N * 2u : 0u);
     for (uint32_t i = 0; i < N; ++i) {
         const pt_triangle& t = d->triangles[i];
+        if (lbvh) {          // Triangle::aabb (triangle.rs:118-122): grow by a, b, c
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = pt_fmin(pt_fmin(pt_fmin(pt_inf(), t.a[k]), t.b[k]), t.c[k]);
+                hi[k] = pt_fmax(pt_fmax(pt_fmax(-pt_inf(), t.a[k]), t.b[k]), t.c[k]);
+            }
+            boxes[2 * (size_t)i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+            boxes[2 * (size_t)i + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+        }
         if (t.material_index >= d->n_materials)
             return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: material_index out of range");
         float ab[3], ac[3], n[3], n1[3], n2[3], tmp[3];
@@ -419,12 +435,25 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
         pt_scene_destroy(ctx, sc.release());
         return rc;
     }
+    ctx->stats = pt_stats{};
+    if (lbvh && N >= 2) {
+        float4 *d_nodes = nullptr, *d_wide = nullptr;
+        uint32_t n_wide = 0;
+        float ms = 0.0f;
+        rc = ptc_build_lbvh(ctx, boxes.data(), N, &d_nodes, &d_wide, &n_wide, &max_depth, &wide_depth, &ms);
+        if (rc != PT_OK) { pt_scene_destroy(ctx, sc.release()); return rc; }
+        s->allocations.push_back(d_nodes); s->allocations.push_back(d_wide);
+        s->view.nodes = d_nodes; s->view.wide = d_wide;
+        s->info.device_bytes += (size_t)(N - 1) * 64u + (size_t)n_wide * 128u;
+        n_internal = N - 1;
+        ctx->stats.total_ms = ms;
+    }
     s->d_sky = const_cast<DevSky*>(d_sky);
     s->view.n_tris = N;
     s->view.n_materials = d->n_materials;
     s->view.max_depth = max_depth;
     s->view.wide_depth = wide_depth;
-    s->view.root_ref = (N == 1) ? (PTC_LEAF_BIT | d->nodes[0].shape_index) : 0u;
+    s->view.root_ref = (N == 1) ? (PTC_LEAF_BIT | (lbvh ? 0u : d->nodes[0].shape_index)) : 0u;
     s->info.n_triangles = N;
     s->info.n_internal_nodes = n_internal;
     s->info.max_depth = max_depth;

@@ -122,4 +122,8 @@ int ptc_timed_event(pt_ctx* ctx, size_t i);
 int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
                      const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out);
 
+// lbvh.hip: device-side build into the layouts above (boxes: {min,0},{max,0} per triangle, host memory)
+int ptc_build_lbvh(pt_ctx* ctx, const float4* h_boxes, uint32_t n, float4** d_nodes, float4** d_wide, uint32_t* n_wide,
+                   uint32_t* max_depth, uint32_t* wide_depth, float* build_ms);
+
 #endif

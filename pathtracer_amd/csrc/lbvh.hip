@@ -1,0 +1,309 @@
+// lbvh.hip — device-side BVH build.  No counterpart in the reference, whose
+// BVH::build (bvh.rs:134-248) is a host-side binned-SAH recursion; pt_bvh_build restates that one bit
+// for bit and stays the default.  This builder is for callers who want the tree made on the GPU:
+//
+//   1. scene bounds of the triangle boxes (ordered-int atomics)
+//   2. 63-bit Morton code of every box centre (21 bits per axis), radix sort of (code, triangle) pairs
+//   3. Karras' binary radix tree over the sorted codes (ties broken by position)
+//   4. boxes bottom-up: the second thread to reach a node writes the node (the boxes of BOTH children
+//      live in the parent, device_types.h) and carries the union upwards
+//   5. depth of every internal node, then the 4-wide records of PT_TRAVERSE_WIDE: internal nodes at odd
+//      depth (root = 1) become wide nodes, numbered by a prefix sum in node order (root stays 0)
+//
+// Leaf boxes are the exact min/max of the triangle's vertices, as Triangle::aabb (triangle.rs:118-122);
+// the tree's TOPOLOGY differs from the reference builder's, so traversal order differs; the minimum-t
+// hit is the same (every triangle is in exactly one leaf, every box bounds its subtree), only exact
+// equal-t ties can resolve differently.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "device_types.h"
+#include "../../include/pt_math.h"
+
+#define LB_BLOCK 256
+
+namespace {
+
+// order-preserving float <-> uint (for atomicMin/atomicMax on floats of either sign)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t o) {
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    float f;
+#ifdef __HIP_DEVICE_COMPILE__
+    f = __uint_as_float(u);
+#else
+    memcpy(&f, &u, 4);
+#endif
+    return f;
+}
+
+// bounds[0..2] = min of box centres (ordered), bounds[3..5] = max
+__global__ __launch_bounds__(LB_BLOCK) void k_bounds(const float4* __restrict__ box, uint32_t n, uint32_t* __restrict__ bounds) {
+    float lo[3] = {pt_inf(), pt_inf(), pt_inf()}, hi[3] = {-pt_inf(), -pt_inf(), -pt_inf()};
+    for (uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x; i < n; i += gridDim.x * LB_BLOCK) {
+        const float4 a = box[2u * i], b = box[2u * i + 1u];
+        const float c[3] = {0.5f * a.x + 0.5f * b.x, 0.5f * a.y + 0.5f * b.y, 0.5f * a.z + 0.5f * b.z};
+        for (int k = 0; k < 3; ++k) {
+            if (c[k] < lo[k]) lo[k] = c[k];
+            if (c[k] > hi[k]) hi[k] = c[k];
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+        if ((threadIdx.x & 63u) == 0u) {
+            atomicMin(&bounds[k], f2ord(lo[k]));
+            atomicMax(&bounds[3 + k], f2ord(hi[k]));
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {       // 21 bits -> every third bit
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(LB_BLOCK) void k_morton(const float4* __restrict__ box, uint32_t n, const uint32_t* __restrict__ bounds,
+                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = box[2u * i], b = box[2u * i + 1u];
+    const float c[3] = {0.5f * a.x + 0.5f * b.x, 0.5f * a.y + 0.5f * b.y, 0.5f * a.z + 0.5f * b.z};
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = ord2f(bounds[k]), hi = ord2f(bounds[3 + k]);
+        const float ext = hi - lo;
+        float t = ext > 0.0f ? (c[k] - lo) / ext : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);             // NaN centres (degenerate input) land in cell 0
+        q[k] = (uint32_t)(t * 2097151.0f);
+    }
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    vals[i] = i;
+}
+
+// Karras 2012: common-prefix length of sorted keys i and j; equal keys fall back to the positions
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, uint32_t n, int i, int j) {
+    if (j < 0 || j >= (int)n) return -1;
+    const uint64_t x = keys[i] ^ keys[j];
+    if (x) return __clzll((long long)x);
+    return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+}
+
+// one thread per internal node i in [0, n-1): children + parent links.
+// child refs use the device encoding: PTC_LEAF_BIT | triangle, or the internal node's index
+__global__ __launch_bounds__(LB_BLOCK) void k_radix_tree(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+                                                         uint2* __restrict__ children, uint32_t* __restrict__ parent_of_internal,
+                                                         uint32_t* __restrict__ parent_of_leaf) {
+    const int i = (int)(blockIdx.x * LB_BLOCK + threadIdx.x);
+    if (i >= (int)n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int div = 2, t = (l + 1) / 2;; div *= 2, t = (l + div - 1) / div) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int split = i + s * d + (d < 0 ? -1 : 0);
+    const int first = d > 0 ? i : j, last = d > 0 ? j : i;
+    uint32_t lref, rref;
+    if (split == first) { lref = PTC_LEAF_BIT | vals[split]; parent_of_leaf[split] = (uint32_t)i; }
+    else { lref = (uint32_t)split; parent_of_internal[split] = (uint32_t)i; }
+    if (split + 1 == last) { rref = PTC_LEAF_BIT | vals[split + 1]; parent_of_leaf[split + 1] = (uint32_t)i; }
+    else { rref = (uint32_t)(split + 1); parent_of_internal[split + 1] = (uint32_t)i; }
+    children[i] = make_uint2(lref, rref);
+    if (i == 0) parent_of_internal[0] = 0xFFFFFFFFu;
+}
+
+// one thread per leaf (sorted position): climb; the SECOND arrival at a node owns it
+__global__ __launch_bounds__(LB_BLOCK) void k_fit(const float4* __restrict__ box, const uint32_t* __restrict__ vals, uint32_t n,
+                                                  const uint2* __restrict__ children, const uint32_t* __restrict__ parent_of_internal,
+                                                  const uint32_t* __restrict__ parent_of_leaf, uint32_t* __restrict__ arrived,
+                                                  float4* __restrict__ node_box, float4* __restrict__ nodes) {
+    const uint32_t p = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    uint32_t cur = parent_of_leaf[p];
+    while (cur != 0xFFFFFFFFu) {
+        __threadfence();
+        if (atomicAdd(&arrived[cur], 1u) == 0u) return;          // first arrival: the sibling subtree is not done
+        __threadfence();
+        const uint2 ch = children[cur];
+        float4 b[4];
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t ref = side ? ch.y : ch.x;
+            const float4* src = (ref & PTC_LEAF_BIT) ? &box[2u * (ref & PTC_INDEX_MASK)] : &node_box[2u * ref];
+            if (ref & PTC_LEAF_BIT) {                  // leaf boxes were uploaded before the launch
+                b[2 * side] = src[0];
+                b[2 * side + 1] = src[1];
+            } else {
+                // written by another thread of THIS launch (before its fence + atomic): device-scope loads, so that a
+                // stale L1 line (a neighbour's box read earlier shares the 128-byte line) cannot be served
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(src);
+                float v[8];
+                for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(__hip_atomic_load(w + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                b[2 * side] = make_float4(v[0], v[1], v[2], 0.0f);
+                b[2 * side + 1] = make_float4(v[4], v[5], v[6], 0.0f);
+            }
+        }
+        float4* q = &nodes[4u * (size_t)cur];
+        q[0] = make_float4(b[0].x, b[0].y, b[0].z, __uint_as_float(ch.x));
+        q[1] = make_float4(b[1].x, b[1].y, b[1].z, __uint_as_float(ch.y));
+        q[2] = make_float4(b[2].x, b[2].y, b[2].z, 0.0f);
+        q[3] = make_float4(b[3].x, b[3].y, b[3].z, 0.0f);
+        // AABB::join (bvh.rs:50-62): component-wise min / max
+        node_box[2u * cur] = make_float4(fminf(b[0].x, b[2].x), fminf(b[0].y, b[2].y), fminf(b[0].z, b[2].z), 0.0f);
+        node_box[2u * cur + 1u] = make_float4(fmaxf(b[1].x, b[3].x), fmaxf(b[1].y, b[3].y), fmaxf(b[1].z, b[3].z), 0.0f);
+        cur = parent_of_internal[cur];
+    }
+}
+
+// depth of internal node i (root = 1); is_wide[i] = depth odd; stats[0] = max depth
+__global__ __launch_bounds__(LB_BLOCK) void k_depth(const uint32_t* __restrict__ parent_of_internal, uint32_t n_internal,
+                                                    uint32_t* __restrict__ is_wide, uint32_t* __restrict__ stats) {
+    const uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (i >= n_internal) return;
+    uint32_t d = 1u;
+    for (uint32_t c = parent_of_internal[i]; c != 0xFFFFFFFFu; c = parent_of_internal[c]) ++d;
+    is_wide[i] = d & 1u;
+    atomicMax(&stats[0], d);
+}
+
+// wide record of every odd-depth internal node (layout: device_types.h)
+__global__ __launch_bounds__(LB_BLOCK) void k_wide(const float4* __restrict__ nodes, const uint32_t* __restrict__ is_wide,
+                                                   const uint32_t* __restrict__ wide_index, uint32_t n_internal, float4* __restrict__ wide) {
+    const uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (i >= n_internal || !is_wide[i]) return;
+    const float nan = __uint_as_float(0x7FC00000u);
+    float lo[3][4], hi[3][4];
+    uint32_t refs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (int a = 0; a < 3; ++a) for (int k = 0; k < 4; ++k) { lo[a][k] = nan; hi[a][k] = nan; }
+    int nch = 0;
+    auto take = [&](const float4* q, int side) {
+        const float4 l = q[side ? 2 : 0], h = q[side ? 3 : 1];
+        lo[0][nch] = l.x; lo[1][nch] = l.y; lo[2][nch] = l.z; hi[0][nch] = h.x; hi[1][nch] = h.y; hi[2][nch] = h.z;
+        const uint32_t r = __float_as_uint(side ? q[1].w : q[0].w);
+        refs[nch] = (r & PTC_LEAF_BIT) ? r : wide_index[r];
+        ++nch;
+    };
+    const float4* q = &nodes[4u * (size_t)i];
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t r = __float_as_uint(side ? q[1].w : q[0].w);
+        if (r & PTC_LEAF_BIT) take(q, side);
+        else { const float4* q2 = &nodes[4u * (size_t)r]; take(q2, 0); take(q2, 1); }
+    }
+    float4* w = &wide[8u * (size_t)wide_index[i]];
+    for (int a = 0; a < 3; ++a) {
+        w[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+        w[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+    }
+    w[6] = make_float4(__uint_as_float(refs[0]), __uint_as_float(refs[1]), __uint_as_float(refs[2]), __uint_as_float(refs[3]));
+    w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+struct Scratch {                     // frees what it holds when the build leaves, however it leaves
+    std::vector<void*> p;
+    ~Scratch() { for (void* q : p) (void)hipFree(q); }
+    template <class T>
+    int get(pt_ctx* ctx, T** out, size_t count, const char* what) {
+        void* q = nullptr;
+        const int rc = ptc_hip(ctx, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)), what);
+        if (rc != PT_OK) return rc;
+        p.push_back(q);
+        *out = (T*)q;
+        return PT_OK;
+    }
+};
+
+}  // namespace
+
+// boxes: 2 float4 per triangle {min.xyz,0},{max.xyz,0} (host).  On success *d_nodes ([n-1][4]) and *d_wide
+// ([*n_wide][8]) are device arrays the caller owns (hipFree), depths as DevSceneView wants them.  n >= 2.
+int ptc_build_lbvh(pt_ctx* ctx, const float4* h_boxes, uint32_t n, float4** d_nodes, float4** d_wide, uint32_t* n_wide,
+                   uint32_t* max_depth, uint32_t* wide_depth, float* build_ms) {
+    *d_nodes = nullptr; *d_wide = nullptr;
+    hipStream_t s = ctx->stream;
+    const uint32_t ni = n - 1u;
+    Scratch tmp;
+    float4 *box = nullptr, *node_box = nullptr;
+    uint64_t *keys = nullptr, *keys2 = nullptr;
+    uint32_t *vals = nullptr, *vals2 = nullptr, *bounds = nullptr, *par_i = nullptr, *par_l = nullptr, *arrived = nullptr, *is_wide = nullptr,
+             *wide_index = nullptr, *stats = nullptr;
+    uint2* children = nullptr;
+    int rc;
+    if ((rc = tmp.get(ctx, &box, 2 * (size_t)n, "lbvh boxes")) || (rc = tmp.get(ctx, &node_box, 2 * (size_t)ni, "lbvh node boxes")) ||
+        (rc = tmp.get(ctx, &keys, n, "lbvh keys")) || (rc = tmp.get(ctx, &keys2, n, "lbvh keys")) ||
+        (rc = tmp.get(ctx, &vals, n, "lbvh values")) || (rc = tmp.get(ctx, &vals2, n, "lbvh values")) ||
+        (rc = tmp.get(ctx, &bounds, 8, "lbvh bounds")) || (rc = tmp.get(ctx, &par_i, ni, "lbvh parents")) ||
+        (rc = tmp.get(ctx, &par_l, n, "lbvh parents")) || (rc = tmp.get(ctx, &arrived, ni, "lbvh counters")) ||
+        (rc = tmp.get(ctx, &is_wide, ni, "lbvh flags")) || (rc = tmp.get(ctx, &wide_index, ni, "lbvh wide index")) ||
+        (rc = tmp.get(ctx, &stats, 4, "lbvh stats")) || (rc = tmp.get(ctx, &children, ni, "lbvh children")))
+        return rc;
+    float4* nodes = nullptr;
+    PTC_HIP(ctx, hipMalloc((void**)&nodes, (size_t)ni * 4u * sizeof(float4)));
+    struct Owned { float4* p; ~Owned() { if (p) (void)hipFree(p); } } own_nodes{nodes}, own_wide{nullptr};
+
+    PTC_HIP(ctx, hipMemcpyAsync(box, h_boxes, 2 * (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s));
+    PTC_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+    const uint32_t init_bounds[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+    PTC_HIP(ctx, hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, s));
+    PTC_HIP(ctx, hipMemsetAsync(arrived, 0, (size_t)ni * sizeof(uint32_t), s));
+    PTC_HIP(ctx, hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), s));
+    const uint32_t gn = (n + LB_BLOCK - 1) / LB_BLOCK, gi = (ni + LB_BLOCK - 1) / LB_BLOCK;
+    hipLaunchKernelGGL(k_bounds, dim3(std::min<uint32_t>(gn, (uint32_t)ctx->n_cus * 8u)), dim3(LB_BLOCK), 0, s, box, n, bounds);
+    hipLaunchKernelGGL(k_morton, dim3(gn), dim3(LB_BLOCK), 0, s, box, n, bounds, keys, vals);
+    size_t sort_bytes = 0;
+    PTC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, s));
+    void* sort_tmp = nullptr;
+    if ((rc = tmp.get(ctx, (char**)&sort_tmp, sort_bytes, "lbvh sort workspace"))) return rc;
+    PTC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys, keys2, vals, vals2, (int)n, 0, 63, s));
+    hipLaunchKernelGGL(k_radix_tree, dim3(gi), dim3(LB_BLOCK), 0, s, keys2, vals2, n, children, par_i, par_l);
+    hipLaunchKernelGGL(k_fit, dim3(gn), dim3(LB_BLOCK), 0, s, box, vals2, n, children, par_i, par_l, arrived, node_box, nodes);
+    hipLaunchKernelGGL(k_depth, dim3(gi), dim3(LB_BLOCK), 0, s, par_i, ni, is_wide, stats);
+    size_t scan_bytes = 0;
+    PTC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_wide, wide_index, (int)ni, s));
+    void* scan_tmp = nullptr;
+    if ((rc = tmp.get(ctx, (char**)&scan_tmp, scan_bytes, "lbvh scan workspace"))) return rc;
+    PTC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, is_wide, wide_index, (int)ni, s));
+    // number of wide nodes = wide_index[last] + is_wide[last]; max depth from stats
+    uint32_t h_last[2] = {0, 0}, h_stats[4] = {0, 0, 0, 0};
+    PTC_HIP(ctx, hipMemcpyAsync(&h_last[0], wide_index + (ni - 1u), 4, hipMemcpyDeviceToHost, s));
+    PTC_HIP(ctx, hipMemcpyAsync(&h_last[1], is_wide + (ni - 1u), 4, hipMemcpyDeviceToHost, s));
+    PTC_HIP(ctx, hipMemcpyAsync(h_stats, stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+    PTC_HIP(ctx, hipStreamSynchronize(s));
+    const uint32_t nw = h_last[0] + h_last[1];
+    if (nw == 0 || h_stats[0] == 0) return ptc_fail(ctx, PT_ERR_HIP, "lbvh: build produced no nodes");
+    float4* wide = nullptr;
+    PTC_HIP(ctx, hipMalloc((void**)&wide, (size_t)nw * 8u * sizeof(float4)));
+    own_wide.p = wide;
+    hipLaunchKernelGGL(k_wide, dim3(gi), dim3(LB_BLOCK), 0, s, nodes, is_wide, wide_index, ni, wide);
+    PTC_HIP(ctx, hipGetLastError());
+    PTC_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+    PTC_HIP(ctx, hipStreamSynchronize(s));
+    float ms = 0.0f;
+    PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    if (build_ms) *build_ms = ms;
+    *max_depth = h_stats[0];
+    *wide_depth = (h_stats[0] + 1u) / 2u;
+    *n_wide = nw;
+    *d_nodes = nodes; *d_wide = wide;
+    own_nodes.p = nullptr; own_wide.p = nullptr;
+    return PT_OK;
+}

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from pathtracer_amd import abi, core, workloads
+from tests.golden import fixture_inputs as fi
 
 pytestmark = pytest.mark.gpu
 
@@ -150,3 +151,66 @@ def test_bad_scene_is_an_error_code(gpu_ctx):
     with pytest.raises(core.PtError) as e:
         gpu_ctx.scene(bad3)
     assert e.value.code == abi.PT_ERR_INVALID and "pt_scene_create" in str(e.value)
+
+
+# ---- device-side BVH build (pt_scene_create_ex, PT_SCENE_BUILD_LBVH) --------------------------------------
+
+def same_up_to_ties(got, want):
+    """Another tree over the same triangles: the hit DISTANCE is the same to the bit on every ray; the triangle
+    (hence u, v) may differ only where two triangles are hit at exactly that distance (soup-1M at 1080p: 1 ray of
+    2 073 600, tools/lbvh_bench.py)."""
+    assert got["t"].tobytes() == want["t"].tobytes()
+    tie = got["tri"] != want["tri"]
+    assert tie.sum() <= 2 and not (tie & ((got["tri"] == abi.PT_NO_TRIANGLE) | (want["tri"] == abi.PT_NO_TRIANGLE))).any()
+    assert got[~tie].tobytes() == want[~tie].tobytes()
+
+
+@pytest.mark.parametrize("n_tris", [2, 3, 5, 64, 20_000, 300_000])
+def test_lbvh_scene_returns_the_same_hits(oracle, gpu_ctx, n_tris):
+    """Another topology, same triangles: the minimum-t hit is the same, to the bit, in every traversal mode."""
+    arr = workloads.soup_scene(n_tris)
+    gsc = gpu_ctx.scene(arr, lbvh=True)
+    assert gsc.info().n_internal_nodes == n_tris - 1 and gsc.info().max_depth >= int(np.ceil(np.log2(n_tris)))
+    rays = core.gen_primary_rays(320, 180)
+    want = oracle.trace(oracle.scene(arr), rays)
+    for mode in MODES:
+        gpu_ctx.set_traversal(mode)
+        same_up_to_ties(gpu_ctx.trace(gsc, rays), want)
+    gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
+    hit = want["tri"] != abi.PT_NO_TRIANGLE
+    if hit.any():
+        brays, start = fi.bounce_rays(rays, want)
+        same_up_to_ties(gpu_ctx.trace(gsc, brays, start), oracle.trace(oracle.scene(arr), brays, start))
+
+
+def test_lbvh_duplicate_centres_and_degenerate_extent(oracle, gpu_ctx):
+    """Every Morton key equal (all triangles share one box centre) and a zero-extent axis: the radix tree falls
+    back to positions and still holds every triangle once."""
+    arr = workloads.soup_scene(500)
+    t = arr.triangles.copy()
+    c = (np.minimum(np.minimum(t["a"], t["b"]), t["c"]) + np.maximum(np.maximum(t["a"], t["b"]), t["c"])) * np.float32(0.5)
+    shift = np.array([0, 0, -3], dtype=np.float32) - c
+    for k in "abc":
+        t[k] += shift
+    arr2 = abi.SceneArrays(t, core.bvh_build(t), arr.materials, arr.sky)
+    rays = core.gen_primary_rays(128, 72)
+    want = oracle.trace(oracle.scene(arr2), rays)
+    got = gpu_ctx.trace(gpu_ctx.scene(arr2, lbvh=True), rays)
+    assert got["t"].tobytes() == want["t"].tobytes()          # an equal-t tie may pick another triangle; the distance may not differ
+    assert (got["tri"] != want["tri"]).mean() < 0.01 and (want["tri"] != abi.PT_NO_TRIANGLE).mean() > 0.02
+
+
+def test_lbvh_render_matches_the_oracle(oracle, gpu_ctx):
+    arr = workloads.soup_scene(20_000, sky=workloads.hw_sky())
+    got = gpu_ctx.render(gpu_ctx.scene(arr, lbvh=True), 80, 45, 0, 4, 4, seed=1)
+    want = oracle.render(oracle.scene(arr), 80, 45, 0, 4, 4, seed=1)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want))
+
+
+def test_lbvh_rejects_nodes(gpu_ctx):
+    arr = workloads.soup_scene(100)
+    d = arr.desc()
+    h = core.C.c_void_p()
+    rc = core.lib().pt_scene_create_ex(gpu_ctx.handle, core.C.byref(d), abi.PT_SCENE_BUILD_LBVH, core.C.byref(h))
+    assert rc == abi.PT_ERR_INVALID
