@@ -19,6 +19,8 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--fast-only", action="store_true")
 ap.add_argument("--bounce", action="store_true", help="time incoherent secondary rays (tests/golden/fixture_inputs.bounce_rays) instead of primaries")
+ap.add_argument("--sort", choices=["none", "origin", "origin+octant", "octant"], default="none",
+                help="with --bounce: reorder the secondary rays by a 30-bit Morton key of the origin and/or the direction octant")
 ap.add_argument("--tile", type=int, default=0, help="reorder rays into TxT pixel tiles")
 a = ap.parse_args()
 
@@ -40,6 +42,20 @@ if a.bounce:
     from tests.golden import fixture_inputs as fi
     first = ctx.trace(sc, rays)
     rays, start = fi.bounce_rays(rays, first)
+    if a.sort != "none":
+        o = rays["o"]
+        q = np.clip(((o - o.min(axis=0)) / (np.ptp(o, axis=0) + 1e-20) * 1023).astype(np.uint64), 0, 1023)
+
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        morton = (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
+        octant = ((rays["d"][:, 0] < 0).astype(np.uint64) << 2) | ((rays["d"][:, 1] < 0).astype(np.uint64) << 1) | (rays["d"][:, 2] < 0).astype(np.uint64)
+        key = {"origin": morton, "origin+octant": (octant << 30) | morton, "octant": octant}[a.sort]
+        order = np.argsort(key, kind="stable")
+        rays, start = np.ascontiguousarray(rays[order]), np.ascontiguousarray(start[order])
     d_start = torch.from_numpy(start.view(np.int32)).cuda()
     d_start_ptr = d_start.data_ptr()
 n = rays.size
