@@ -194,8 +194,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
 
     for (uint32_t k = gtid; k < n; k += total_threads) {
         const uint32_t i = QUEUED ? queue[k] : k;
-        const float4 ro = rays[2u * i];
-        const DRay r = make_ray(ro, rays[2u * i + 1u]);
+        const float4 ro = rays[2 * (size_t)i];
+        const DRay r = make_ray(ro, rays[2 * (size_t)i + 1]);
         // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
         const uint32_t skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[i] : PT_NO_TRIANGLE);
         float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
             if (!has_ray && rank < avail) {
                 const uint32_t k = blk_next + rank;
                 ray_i = QUEUED ? queue[k] : k;
-                const float4 ro = rays[2u * ray_i];
-                r = make_ray(ro, rays[2u * ray_i + 1u]);
+                const float4 ro = rays[2 * (size_t)ray_i];
+                r = make_ray(ro, rays[2 * (size_t)ray_i + 1]);
                 // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
                 skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[ray_i] : PT_NO_TRIANGLE);
                 best_t = pt_inf(); best_u = 0.0f; best_v = 0.0f; best_id = PT_NO_TRIANGLE;
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, cons
 
     for (uint32_t k = gtid; k < n; k += total_threads) {
         const uint32_t i = QUEUED ? queue[k] : k;
-        const float4 ro = rays[2u * i];
-        const DRay r = make_ray(ro, rays[2u * i + 1u]);
+        const float4 ro = rays[2 * (size_t)i];
+        const DRay r = make_ray(ro, rays[2 * (size_t)i + 1]);
         // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
         const uint32_t skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[i] : PT_NO_TRIANGLE);
         // value being returned up the (virtual) call stack: None = {NONE_ID, +inf}

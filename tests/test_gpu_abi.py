@@ -112,3 +112,33 @@ def test_same_seed_same_image_different_seed_different_image(gpu_ctx):
     d = gpu_ctx.render(sc, 64, 48, 0, 2, 2, seed=11 + (1 << 32))
     assert a.tobytes() == b.tobytes()
     assert a.tobytes() != c.tobytes() and a.tobytes() != d.tobytes()
+
+
+def test_batch_beyond_2_to_31_rays(gpu_ctx):
+    """Ray index arithmetic is 64-bit: a batch of 2^31 + 8192 rays (64 GiB of rays, 32 GiB of hits, resident in HBM)
+    gives the same hits at its far end as the same rays traced on their own."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    n = (1 << 31) + 8192
+    if free < n * 48 + (8 << 30):
+        pytest.skip("needs ~105 GB of free HBM")
+    arr = workloads.soup_scene(20_000)
+    sc = gpu_ctx.scene(arr)
+    prim = core.gen_primary_rays(64, 64)                       # 4096 rays
+    want = gpu_ctx.trace(sc, prim)
+    d_prim = torch.from_numpy(prim.view(np.float32).reshape(-1, 8)).cuda()
+    d_rays = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    # far-away rays that miss at once everywhere, the probe rays in the last 4096 slots and across the 2^31 boundary
+    d_rays.zero_()
+    d_rays[:, 1] = 1.0e6
+    d_rays[:, 5] = 1.0
+    d_rays[n - 4096:] = d_prim
+    d_rays[(1 << 31) - 2048:(1 << 31) + 2048] = d_prim
+    d_hits = torch.full((n, 4), 0x55, dtype=torch.int32, device="cuda")
+    gpu_ctx.trace_dev(sc, d_rays.data_ptr(), 0, n, d_hits.data_ptr())
+    tail = d_hits[n - 4096:].cpu().numpy().view(abi.HIT).reshape(-1)
+    mid = d_hits[(1 << 31) - 2048:(1 << 31) + 2048].cpu().numpy().view(abi.HIT).reshape(-1)
+    assert tail.tobytes() == want.tobytes() and mid.tobytes() == want.tobytes()
+    assert int((d_hits[:1 << 20, 0] != -1).sum()) == 0         # the filler rays miss (tri = 0xFFFFFFFF)
+    del d_rays, d_hits
+    torch.cuda.empty_cache()
