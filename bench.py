@@ -210,12 +210,23 @@ def main():
         achieved = b_ray * n / (kernel_ms_avg * 1e-3) / 1e9
         # HBM-side bytes per launch from the PMC passes of tools/profile_bench.sh on this same command
         # (profiles/traffic.json; null until that file matches this workload)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, tj = None, None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("traversal") == a.traversal and tj.get("tris") == a.tris and tj.get("rays") == n:
                 traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+        issue = None
+        if traffic is not None and tj.get("SQ_INSTS_VALU"):
+            # secondary bound, from the same profile: VALU issue.  1024 SIMDs, one wave64 VALU instruction per 4 cycles
+            # each; clock taken from the profile's own GRBM_GUI_ACTIVE (summed over 8 XCDs) over its kernel time.
+            peak = 1024 / 4 * 2.4e9
+            issue = {"bound": "valu-issue", "valu_wave_instructions_per_launch": tj["SQ_INSTS_VALU"],
+                     "achieved": tj["SQ_INSTS_VALU"] / (kernel_ms_avg * 1e-3), "peak": peak, "unit": "wave-instr/s",
+                     "frac": tj["SQ_INSTS_VALU"] / (kernel_ms_avg * 1e-3) / peak,
+                     "active_lanes_per_valu_instruction": (tj["SQ_THREAD_CYCLES_VALU"] / tj["SQ_INSTS_VALU"]) if tj.get("SQ_THREAD_CYCLES_VALU") else None,
+                     "wave_cycles_waiting_frac": (tj["SQ_WAIT_ANY"] / tj["SQ_WAVE_CYCLES"]) if tj.get("SQ_WAVE_CYCLES") else None,
+                     "note": "instruction counts from profiles/traffic.json (rocprofv3 --pmc), time measured live; 2.4 GHz assumed"}
         roofline = {
             "bound": "hbm", "kernel": "k_trace_exact" if a.traversal == "exact" else f"k_trace_fast_persistent ({a.traversal})",
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -223,6 +234,7 @@ def main():
             "bytes_per_ray": b_ray, "n_node": n_node, "n_tri": n_tri, "visit_counts": counts_src,
             "kernel_ms": kernel_ms_avg,
             "algorithmic_bytes_per_launch": b_ray * n,
+            "issue_side": issue,
             "note": "achieved = algorithmic bytes (B_ray = 32 + 16 + 64*n_node + 48*n_tri under the REFERENCE's traversal "
                     "rule, SURVEY.md 8d) / kernel time. The ~100 MB node+triangle set is re-read from L1/L2/Infinity Cache, "
                     "so measured HBM-side traffic is a small fraction of the algorithmic bytes and the kernel is bound by "
