@@ -189,3 +189,14 @@ def test_product_never_touches_the_oracle():
     assert not hits, hits
     out = subprocess.check_output(["ldd", os.path.join(pkg, "libptcore.so")]).decode()
     assert "ptoracle" not in out
+
+
+def test_integration_doc_declares_every_entry_point():
+    """INTEGRATION.md shows the reference-side binding: every function of include/ptcore.h appears in it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "ptcore.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    assert [n for n in names if n not in doc] == []
