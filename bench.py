@@ -91,6 +91,7 @@ def main():
     n = rays.size
     d_rays = torch.from_numpy(rays.view(np.float32).reshape(n, 8)).cuda()
     d_hits = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()        # the library runs on its own stream: torch's fills must be complete first
 
     # ---- timed region --------------------------------------------------------------------------
     for _ in range(a.warmup):
@@ -116,6 +117,7 @@ def main():
     if a.spectral_spp > 0:
         spp_total = a.spectral_spp * world          # weak: every rank renders spectral_spp samples
         d_img = torch.zeros((a.height, a.width, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
 
         def render_sum(begin, count):
             ctx.render_dev(scene, a.width, a.height, begin, count, spp_total, 1, abi.PT_RENDER_SUM, d_img.data_ptr())

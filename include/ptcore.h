@@ -202,7 +202,9 @@ void pt_scene_destroy(pt_ctx* ctx, pt_scene* scene);
 int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
                      const uint32_t* start_tri, uint32_t n, pt_hit* out);
 /* Same with DEVICE pointers (rays/hits already resident in HBM); returns after the kernel has
- * completed. */
+ * completed.  The library works on a stream of its own: whatever the caller has queued on other streams
+ * that writes d_rays / d_start_tri / d_out must be complete before the call (this holds for every
+ * *_dev entry point). */
 int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
                          const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out);
 

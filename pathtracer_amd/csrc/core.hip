@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 
 #include "device_types.h"
 #include "tables.h"
@@ -325,7 +327,9 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
 
     // ---- Triangle::new (triangle.rs:50-60) ---------------------------------------------------------
     std::vector<float4> tris((size_t)N * 3u), shade((size_t)N * 5u), boxes(lbvh ? (size_t)N * 2u : 0u);
-    for (uint32_t i = 0; i < N; ++i) {
+    std::atomic<bool> bad_material{false};
+    auto precompute = [&](uint32_t begin, uint32_t end) {
+    for (uint32_t i = begin; i < end; ++i) {
         const pt_triangle& t = d->triangles[i];
         if (lbvh) {          // Triangle::aabb (triangle.rs:118-122): grow by a, b, c
             float lo[3], hi[3];
@@ -336,8 +340,7 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
             boxes[2 * (size_t)i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
             boxes[2 * (size_t)i + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
         }
-        if (t.material_index >= d->n_materials)
-            return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: material_index out of range");
+        if (t.material_index >= d->n_materials) { bad_material = true; return; }
         float ab[3], ac[3], n[3], n1[3], n2[3], tmp[3];
         for (int k = 0; k < 3; ++k) { ab[k] = t.b[k] - t.a[k]; ac[k] = t.c[k] - t.a[k]; }
         cross3(ab, ac, n);
@@ -362,6 +365,20 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
         s[3] = make_float4(t.vertex_normals[1][1], t.vertex_normals[1][2], t.vertex_normals[2][0], t.vertex_normals[2][1]);
         s[4] = make_float4(t.vertex_normals[2][2], 0.0f, 0.0f, 0.0f);
     }
+    };
+    {   // every triangle is independent: split the range over the host's cores (at most 16)
+        const uint32_t nt = N < (1u << 16) ? 1u : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        const uint32_t chunk = (N + nt - 1u) / nt;
+        for (uint32_t k = 1; k < nt; ++k)
+            if (k * chunk < N) {
+                try { pool.emplace_back(precompute, k * chunk, std::min(N, (k + 1u) * chunk)); }
+                catch (...) { precompute(k * chunk, std::min(N, (k + 1u) * chunk)); }       // no thread to be had: do it here
+            }
+        precompute(0u, std::min(N, chunk));
+        for (auto& th : pool) th.join();
+    }
+    if (bad_material) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: material_index out of range");
 
     // ---- materials, images ---------------------------------------------------------------------------
     std::vector<DevImage> images(d->n_images);

@@ -92,12 +92,14 @@ def test_device_pointer_entry_points_match_host_pointer_ones(gpu_ctx):
     want = gpu_ctx.trace(sc, rays)
     d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 8)).cuda()
     d_out = torch.zeros((rays.size, 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     gpu_ctx.trace_dev(sc, d_rays.data_ptr(), 0, rays.size, d_out.data_ptr())
     st = gpu_ctx.stats()
     assert st.trace_rays == rays.size and st.trace_launches == 1 and st.trace_ms > 0
     assert d_out.cpu().numpy().tobytes() == want.tobytes()
     img = gpu_ctx.render(sc, 96, 54, 0, 2, 2, seed=3)
     d_img = torch.zeros((54, 96, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     gpu_ctx.render_dev(sc, 96, 54, 0, 2, 2, 3, abi.PT_RENDER_FINAL, d_img.data_ptr())
     assert d_img.cpu().numpy().tobytes() == img.tobytes()
     info = sc.info()
@@ -135,6 +137,7 @@ def test_batch_beyond_2_to_31_rays(gpu_ctx):
     d_rays[n - 4096:] = d_prim
     d_rays[(1 << 31) - 2048:(1 << 31) + 2048] = d_prim
     d_hits = torch.full((n, 4), 0x55, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()            # the library runs on its own stream: the caller's fills must be complete
     gpu_ctx.trace_dev(sc, d_rays.data_ptr(), 0, n, d_hits.data_ptr())
     tail = d_hits[n - 4096:].cpu().numpy().view(abi.HIT).reshape(-1)
     mid = d_hits[(1 << 31) - 2048:(1 << 31) + 2048].cpu().numpy().view(abi.HIT).reshape(-1)

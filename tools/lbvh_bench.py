@@ -38,6 +38,7 @@ rays = core.gen_primary_rays(w, h)
 n = rays.size
 d_rays = torch.from_numpy(rays.view(np.float32).reshape(n, 8)).cuda()
 d_hits = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
 out = {"triangles": int(tris.size), "host_sah_build_s": host_build_s, "scene_create_with_host_nodes_s": sah_create_s,
        "scene_create_lbvh_s": lbvh_create_s, "lbvh_device_build_ms": lbvh_device_ms,
        "depth": {"sah": sah.info().max_depth, "lbvh": lb.info().max_depth}}

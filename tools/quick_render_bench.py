@@ -24,6 +24,7 @@ arr = workloads.soup_scene(a.tris, sky=workloads.hw_sky())
 ctx = core.Context(0)
 sc = ctx.scene(arr)
 d_img = torch.zeros((a.height, a.width, 4), dtype=torch.float32, device="cuda")
+torch.cuda.synchronize()
 ctx.render_dev(sc, a.width, a.height, 0, 1, 1, 1, abi.PT_RENDER_FINAL, d_img.data_ptr())
 for r in range(a.reps):
     torch.cuda.synchronize()

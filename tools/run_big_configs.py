@@ -41,6 +41,7 @@ def time_trace(gsc, rays, start=None, reps=10):
     n = rays.size
     d_rays = torch.from_numpy(rays.view(np.float32).reshape(n, 8)).cuda()
     d_out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     d_start = None if start is None else torch.from_numpy(start.view(np.int32)).cuda()
     ms = []
     for _ in range(reps + 2):
@@ -53,6 +54,7 @@ if not a.skip_4k:
     arr = workloads.soup_scene(1_000_000, sky=workloads.hw_sky())
     gsc = ctx.scene(arr)
     d_img = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     ctx.render_dev(gsc, W, H, 0, 4, a.spp4k, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
     torch.cuda.synchronize(); t = time.perf_counter()
     ctx.render_dev(gsc, W, H, 0, a.spp4k, a.spp4k, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
@@ -96,6 +98,7 @@ if not a.skip_20m:
     out.update(par)
     print(json.dumps(out), flush=True)
     d_img = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     ctx.render_dev(gsc, W, H, 0, 2, 4, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
     torch.cuda.synchronize(); t = time.perf_counter()
     ctx.render_dev(gsc, W, H, 0, 4, 4, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
