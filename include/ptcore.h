@@ -201,6 +201,12 @@ void pt_scene_destroy(pt_ctx* ctx, pt_scene* scene);
  * start_tri may be NULL; an entry PT_NO_TRIANGLE means `start = None`.  Host pointers. */
 int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
                      const uint32_t* start_tri, uint32_t n, pt_hit* out);
+/* Pinned host memory (no reference counterpart).  pt_trace_closest cuts the batch into chunks and overlaps
+ * upload, kernel and download; with rays / start_tri / out in memory from pt_host_alloc every copy is an
+ * asynchronous DMA and the call runs at PCIe speed, with ordinary (pageable) memory the runtime stages each
+ * copy on the calling thread.  Either kind of pointer is accepted. */
+int  pt_host_alloc(size_t bytes, void** out);
+void pt_host_free(void* p);
 /* Same with DEVICE pointers (rays/hits already resident in HBM); returns after the kernel has
  * completed.  The library works on a stream of its own: whatever the caller has queued on other streams
  * that writes d_rays / d_start_tri / d_out must be complete before the call (this holds for every

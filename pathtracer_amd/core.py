@@ -55,6 +55,8 @@ def lib():
         "pt_scene_get_info": (i32, [vp, C.POINTER(abi.SceneInfo)]),
         "pt_gen_soup": (i32, [u64, u32, C.POINTER(f32), C.POINTER(f32), f32, f32, u32, vp]),
         "pt_gen_primary_rays": (i32, [C.POINTER(abi.Camera), vp]),
+        "pt_host_alloc": (i32, [C.c_size_t, C.POINTER(vp)]),
+        "pt_host_free": (None, [vp]),
         "pt_scene_file_load": (i32, [C.c_char_p, C.POINTER(vp)]),
         "pt_scene_file_get": (i32, [vp, C.POINTER(abi.SceneFileInfo)]),
         "pt_scene_file_free": (None, [vp]),
@@ -73,6 +75,7 @@ EXPORTS = [
     "pt_trace_closest_dev", "pt_set_traversal", "pt_render", "pt_render_dev", "pt_get_stats",
     "pt_scene_get_info", "pt_gen_soup", "pt_gen_primary_rays", "pt_tonemap", "pt_tonemap_dev",
     "pt_scene_file_load", "pt_scene_file_get", "pt_scene_file_free", "pt_scene_create_ex",
+    "pt_host_alloc", "pt_host_free",
 ]
 
 
@@ -171,6 +174,32 @@ def load_scene_file(path):
         lib().pt_scene_file_free(h)
 
 
+class PinnedArray:
+    """A numpy array over pinned host memory from pt_host_alloc (freed with the object)."""
+
+    def __init__(self, shape, dtype):
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * self.dtype.itemsize
+        self._p = C.c_void_p()
+        rc = lib().pt_host_alloc(n, C.byref(self._p))
+        if rc != abi.PT_OK:
+            raise PtError(rc, (lib().pt_last_error(None) or b"").decode())
+        buf = (C.c_char * max(n, 1)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().pt_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- device side ------------------------------------------------------------------------------
 
 class Scene:
@@ -228,10 +257,12 @@ class Context:
     def set_traversal(self, mode):
         self._check(lib().pt_set_traversal(self.handle, int(mode)))
 
-    def trace(self, scene, rays, start=None):
+    def trace(self, scene, rays, start=None, out=None):
         rays = np.ascontiguousarray(rays, dtype=abi.RAY)
         n = rays.size
-        out = np.zeros(n, dtype=abi.HIT)
+        if out is None:
+            out = np.zeros(n, dtype=abi.HIT)
+        assert out.dtype == abi.HIT and out.size == n and out.flags["C_CONTIGUOUS"]
         st = None if start is None else np.ascontiguousarray(start, dtype=np.uint32)
         self._check(lib().pt_trace_closest(self.handle, scene.handle, abi.ptr(rays), abi.ptr(st), n, abi.ptr(out)))
         return out

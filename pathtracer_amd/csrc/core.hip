@@ -90,6 +90,8 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return bad("hipGetDeviceProperties");
     ctx->n_cus = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate");
     for (auto& ev : ctx->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bad("hipEventCreate");
     for (auto& ev : ctx->count_ev)
@@ -106,6 +108,7 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_refill = env_u32("PTC_REFILL", ctx->tune_refill);
     ctx->tune_shade_blocks_per_cu = std::max(1u, env_u32("PTC_SHADE_BLOCKS_PER_CU", ctx->tune_shade_blocks_per_cu));
     ctx->tune_ring = env_u32("PTC_RING", ctx->tune_ring);
+    ctx->tune_host_chunk = std::max(1u << 12, std::min(1u << 28, env_u32("PTC_HOST_CHUNK", ctx->tune_host_chunk)));
     ctx->tune_pass_paths = std::max(1u << 16, std::min(192u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
     guard.p = nullptr;
     *out = ctx;
@@ -124,6 +127,9 @@ extern "C" void pt_shutdown(pt_ctx* ctx) {
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->count_ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->trace_ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->pipe_ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->copy_in) { (void)hipStreamSynchronize(ctx->copy_in); (void)hipStreamDestroy(ctx->copy_in); }
+    if (ctx->copy_out) { (void)hipStreamSynchronize(ctx->copy_out); (void)hipStreamDestroy(ctx->copy_out); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -499,12 +505,17 @@ extern "C" int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt
     return PT_OK;
 }
 
-extern "C" int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
-                                const uint32_t* start_tri, uint32_t n, pt_hit* out) {
-    if (!ctx) return PT_ERR_INVALID;
-    if (!scene || (n && (!rays || !out))) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest: NULL argument");
-    if (n == 0) { ctx->stats = pt_stats{}; return PT_OK; }
-    PTC_HIP(ctx, hipSetDevice(ctx->device));
+// pinned host memory for callers that want the host-pointer entry points to run at PCIe speed
+extern "C" int pt_host_alloc(size_t bytes, void** out) {
+    if (!out) return PT_ERR_INVALID;
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return ptc_fail(nullptr, e == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP, std::string("pt_host_alloc: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+extern "C" void pt_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+static int trace_closest_host(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays, const uint32_t* start_tri, uint32_t n, pt_hit* out) {
     const size_t rb = (size_t)n * sizeof(pt_ray), sb = (size_t)n * sizeof(uint32_t), hb = (size_t)n * sizeof(pt_hit);
     const size_t sb_pad = (sb + 255) & ~(size_t)255;
     int rc = ptc_reserve(ctx, &ctx->io, &ctx->io_bytes, rb + sb_pad + hb, "ray staging");
@@ -513,11 +524,57 @@ extern "C" int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray
     pt_ray* d_rays = (pt_ray*)base;
     uint32_t* d_start = (uint32_t*)(base + rb);
     pt_hit* d_out = (pt_hit*)(base + rb + sb_pad);
-    PTC_HIP(ctx, hipMemcpyAsync(d_rays, rays, rb, hipMemcpyHostToDevice, ctx->stream));
-    if (start_tri) PTC_HIP(ctx, hipMemcpyAsync(d_start, start_tri, sb, hipMemcpyHostToDevice, ctx->stream));
-    rc = pt_trace_closest_dev(ctx, scene, d_rays, start_tri ? d_start : nullptr, n, d_out);
-    if (rc != PT_OK) return rc;
-    PTC_HIP(ctx, hipMemcpyAsync(out, d_out, hb, hipMemcpyDeviceToHost, ctx->stream));
+    // Chunks of 512 Ki rays: the upload of chunk c+1, the kernel of chunk c and the download of chunk c-1 overlap
+    // (three streams chained by events).  With pinned host buffers (pt_host_alloc) every copy is asynchronous and the
+    // call runs at the speed of the slower PCIe direction; pageable buffers make the runtime stage each copy, which
+    // serialises them on the calling thread (the kernels still overlap).
+    const uint32_t CHUNK = ctx->tune_host_chunk;
+    const uint32_t n_chunks = (n + CHUNK - 1u) / CHUNK;
+    while (ctx->pipe_ev.size() < 2u * (size_t)n_chunks) {
+        hipEvent_t e = nullptr;
+        PTC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pipe_ev.push_back(e);
+    }
+    ctx->stats = pt_stats{};
+    PTC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const uint32_t b = c * CHUNK, m = std::min(CHUNK, n - b);
+        PTC_HIP(ctx, hipMemcpyAsync(d_rays + b, rays + b, (size_t)m * sizeof(pt_ray), hipMemcpyHostToDevice, ctx->copy_in));
+        if (start_tri) PTC_HIP(ctx, hipMemcpyAsync(d_start + b, start_tri + b, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->copy_in));
+        PTC_HIP(ctx, hipEventRecord(ctx->pipe_ev[2u * c], ctx->copy_in));
+        PTC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_ev[2u * c], 0));
+        if ((rc = ptc_timed_event(ctx, 2u * c)) != PT_OK) return rc;
+        if ((rc = ptc_launch_trace(ctx, scene, d_rays + b, start_tri ? d_start + b : nullptr, nullptr, nullptr, m, d_out + b)) != PT_OK) return rc;
+        if ((rc = ptc_timed_event(ctx, 2u * c + 1u)) != PT_OK) return rc;
+        PTC_HIP(ctx, hipEventRecord(ctx->pipe_ev[2u * c + 1u], ctx->stream));
+        PTC_HIP(ctx, hipStreamWaitEvent(ctx->copy_out, ctx->pipe_ev[2u * c + 1u], 0));
+        PTC_HIP(ctx, hipMemcpyAsync(out + b, d_out + b, (size_t)m * sizeof(pt_hit), hipMemcpyDeviceToHost, ctx->copy_out));
+    }
+    PTC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    PTC_HIP(ctx, hipStreamSynchronize(ctx->copy_out));
     PTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double trace_ms = 0.0;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        float ms = 0.0f;
+        PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->trace_ev[2u * c], ctx->trace_ev[2u * c + 1u]));
+        trace_ms += ms;
+    }
+    float total = 0.0f;
+    PTC_HIP(ctx, hipEventElapsedTime(&total, ctx->ev[0], ctx->ev[1]));
+    ctx->stats.trace_ms = trace_ms; ctx->stats.total_ms = total;
+    ctx->stats.trace_rays = n; ctx->stats.trace_launches = n_chunks;
     return PT_OK;
+}
+
+extern "C" int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
+                                const uint32_t* start_tri, uint32_t n, pt_hit* out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!scene || (n && (!rays || !out))) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest: NULL argument");
+    if (n == 0) { ctx->stats = pt_stats{}; return PT_OK; }
+    PTC_HIP(ctx, hipSetDevice(ctx->device));
+    const int rc = trace_closest_host(ctx, scene, rays, start_tri, n, out);
+    if (rc != PT_OK) {      // leave nothing in flight that still reads or writes the caller's buffers
+        (void)hipStreamSynchronize(ctx->copy_in); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->copy_out);
+    }
+    return rc;
 }

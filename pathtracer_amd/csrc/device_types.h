@@ -83,6 +83,8 @@ struct pt_scene {
 struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_in = nullptr, copy_out = nullptr;   // pt_trace_closest: uploads / downloads overlapped with the kernel
+    std::vector<hipEvent_t> pipe_ev;     // pt_trace_closest: per chunk {rays uploaded, hits ready} (grown on demand)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t count_ev[8] = {};         // pt_render: one per in-flight live-count readback
     std::vector<hipEvent_t> trace_ev;    // pt_render: pairs around every traversal launch (grown on demand)
@@ -103,6 +105,7 @@ struct pt_ctx {
     uint32_t tune_refill = 16;
     uint32_t tune_shade_blocks_per_cu = 64; // k_shade grid cap (blocks loop over the queue beyond it)
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the persistent traversal kernel
+    uint32_t tune_host_chunk = 512u << 10; // pt_trace_closest: rays per pipelined chunk
     uint32_t tune_pass_paths = 64u << 20; // pt_render: paths in flight per pass (~1.1 KiB of HBM each)
 };
 

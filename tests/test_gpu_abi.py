@@ -145,3 +145,26 @@ def test_batch_beyond_2_to_31_rays(gpu_ctx):
     assert int((d_hits[:1 << 20, 0] != -1).sum()) == 0         # the filler rays miss (tri = 0xFFFFFFFF)
     del d_rays, d_hits
     torch.cuda.empty_cache()
+
+
+def test_host_pointer_path_is_chunked_and_accepts_pinned_memory(oracle, gpu_ctx):
+    """pt_trace_closest pipelines chunks of 512 Ki rays: a batch of several chunks with a ragged tail, with and
+    without start triangles, from pageable and from pinned (pt_host_alloc) buffers."""
+    arr = workloads.soup_scene(20_000)
+    sc, osc = gpu_ctx.scene(arr), oracle.scene(arr)
+    base = core.gen_primary_rays(1280, 720)                       # 921 600 rays
+    rays = np.concatenate([base, base[::-1][:300_001]])           # 1 221 601 rays: 2 full chunks + a tail
+    want = oracle.trace(osc, rays)
+    got = gpu_ctx.trace(sc, rays)
+    assert got.tobytes() == want.tobytes()
+    assert gpu_ctx.stats().trace_launches == 3 and gpu_ctx.stats().trace_rays == rays.size
+    start = np.where(np.arange(rays.size) % 3 == 0, want["tri"], abi.PT_NO_TRIANGLE).astype(np.uint32)
+    want_s = oracle.trace(osc, rays, start)
+    assert gpu_ctx.trace(sc, rays, start).tobytes() == want_s.tobytes()
+    p_rays, p_start, p_out = core.PinnedArray(rays.size, abi.RAY), core.PinnedArray(rays.size, np.uint32), core.PinnedArray(rays.size, abi.HIT)
+    p_rays.array[:] = rays
+    p_start.array[:] = start
+    gpu_ctx.trace(sc, p_rays.array, p_start.array, out=p_out.array)
+    assert p_out.array.tobytes() == want_s.tobytes()
+    for p in (p_rays, p_start, p_out):
+        p.close()

@@ -75,13 +75,24 @@ for mode, name in ((abi.PT_TRAVERSE_FAST, "fast"), (abi.PT_TRAVERSE_WIDE, "wide"
     res[name] = d_out.cpu().numpy().copy()
     print(f"{name}: {np.mean(ms):.3f} ms (min {np.min(ms):.3f}) -> {n/np.mean(ms)/1e3:.1f} Mrays/s", flush=True)
 if not a.bounce:
-    ctx.set_traversal(abi.PT_TRAVERSE_FAST)
-    ctx.trace(sc, rays)
+    ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
+    out = np.zeros(n, dtype=abi.HIT)
+    ctx.trace(sc, rays, out=out)
     t0 = time.perf_counter()
-    for _ in range(3):
-        ctx.trace(sc, rays)
-    dt = (time.perf_counter() - t0) / 3
-    print(f"host-pointer pt_trace_closest (H2D rays + kernel + D2H hits, pageable numpy buffers): {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} Mrays/s", flush=True)
+    for _ in range(5):
+        ctx.trace(sc, rays, out=out)
+    dt = (time.perf_counter() - t0) / 5
+    print(f"host-pointer pt_trace_closest (upload + kernel + download, chunked), pageable numpy buffers: {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} Mrays/s", flush=True)
+    p_rays, p_out = core.PinnedArray(n, abi.RAY), core.PinnedArray(n, abi.HIT)
+    p_rays.array[:] = rays
+    ctx.trace(sc, p_rays.array, out=p_out.array)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.trace(sc, p_rays.array, out=p_out.array)
+    dt = (time.perf_counter() - t0) / 5
+    print(f"host-pointer pt_trace_closest, pinned buffers (pt_host_alloc): {dt*1e3:.2f} ms -> {n/dt/1e6:.1f} Mrays/s; "
+          f"device side {ctx.stats().total_ms:.2f} ms, kernels {ctx.stats().trace_ms:.2f} ms in {ctx.stats().trace_launches} launches; "
+          f"same hits: {p_out.array.tobytes() == out.tobytes()} crc {__import__('zlib').crc32(out.tobytes())}", flush=True)
 import zlib
 print("fast crc", zlib.crc32(res["fast"].tobytes()), "wide crc", zlib.crc32(res["wide"].tobytes()))
 if not a.fast_only:
