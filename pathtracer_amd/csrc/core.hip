@@ -524,7 +524,7 @@ static int trace_closest_host(pt_ctx* ctx, const pt_scene* scene, const pt_ray* 
     pt_ray* d_rays = (pt_ray*)base;
     uint32_t* d_start = (uint32_t*)(base + rb);
     pt_hit* d_out = (pt_hit*)(base + rb + sb_pad);
-    // Chunks of 512 Ki rays: the upload of chunk c+1, the kernel of chunk c and the download of chunk c-1 overlap
+    // Chunks of 1 Mi rays (PTC_HOST_CHUNK): the upload of chunk c+1, the kernel of chunk c and the download of chunk c-1 overlap
     // (three streams chained by events).  With pinned host buffers (pt_host_alloc) every copy is asynchronous and the
     // call runs at the speed of the slower PCIe direction; pageable buffers make the runtime stage each copy, which
     // serialises them on the calling thread (the kernels still overlap).

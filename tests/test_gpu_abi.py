@@ -148,12 +148,12 @@ def test_batch_beyond_2_to_31_rays(gpu_ctx):
 
 
 def test_host_pointer_path_is_chunked_and_accepts_pinned_memory(oracle, gpu_ctx):
-    """pt_trace_closest pipelines chunks of 512 Ki rays: a batch of several chunks with a ragged tail, with and
+    """pt_trace_closest pipelines chunks of 1 Mi rays: a batch of several chunks with a ragged tail, with and
     without start triangles, from pageable and from pinned (pt_host_alloc) buffers."""
     arr = workloads.soup_scene(20_000)
     sc, osc = gpu_ctx.scene(arr), oracle.scene(arr)
     base = core.gen_primary_rays(1280, 720)                       # 921 600 rays
-    rays = np.concatenate([base, base[::-1][:300_001]])           # 1 221 601 rays: 2 full chunks + a tail
+    rays = np.concatenate([base, base[::-1], base[:400_001]])     # 2 243 201 rays: 2 full chunks + a tail
     want = oracle.trace(osc, rays)
     got = gpu_ctx.trace(sc, rays)
     assert got.tobytes() == want.tobytes()
