@@ -96,6 +96,30 @@ struct Sky {
     }
 };
 
+// Pinned host memory (pt_host_alloc): ray / hit buffers kept in one make Scene::traverse run at PCIe speed.
+template <class T>
+class PinnedBuffer {
+public:
+    explicit PinnedBuffer(size_t count) : n_(count) {
+        void* p = nullptr;
+        const int rc = pt_host_alloc(count * sizeof(T), &p);
+        if (rc != PT_OK) throw Error(rc, pt_last_error(nullptr));
+        p_ = static_cast<T*>(p);
+    }
+    ~PinnedBuffer() { pt_host_free(p_); }
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    size_t size() const { return n_; }
+    T& operator[](size_t i) { return p_[i]; }
+    const T& operator[](size_t i) const { return p_[i]; }
+
+private:
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+
 // One GPU (pt_ctx).  One caller thread per Device.
 class Device {
 public:
@@ -178,6 +202,11 @@ public:
         std::vector<Hit> hits(rays.size());
         dev_->check(pt_trace_closest(dev_->handle(), scene_, rays.data(), start ? start->data() : nullptr, (uint32_t)rays.size(), hits.data()));
         return hits;
+    }
+    // the same over caller-owned buffers (pageable or pinned); start may be nullptr
+    void traverse(const Ray* rays, const uint32_t* start, size_t n, Hit* hits) const {
+        if (n > 0xF0000000ull) throw Error(PT_ERR_UNSUPPORTED, "Scene::traverse: more than 0xF0000000 rays in one batch");
+        dev_->check(pt_trace_closest(dev_->handle(), scene_, rays, start, (uint32_t)n, hits));
     }
     // the render closure (main.rs:58-116): X, Y, Z, 1.0 per pixel, index 4*(x + y*W) + c
     std::vector<float> render(const Camera& cam, uint32_t samples, uint64_t seed) const {

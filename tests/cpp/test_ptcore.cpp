@@ -178,6 +178,13 @@ static void traverse_and_render_match_the_oracle(Device& dev) {
     size_t n_hit = 0;
     for (const Hit& h : want) n_hit += h.tri != PT_NO_TRIANGLE;
     CHECK(n_hit > rays.size() / 4);
+    {   // the same batch from pinned buffers
+        PinnedBuffer<Ray> pr(rays.size());
+        PinnedBuffer<Hit> ph(rays.size());
+        std::memcpy(pr.data(), rays.data(), rays.size() * sizeof(Ray));
+        scene.traverse(pr.data(), nullptr, pr.size(), ph.data());
+        CHECK(same_bits(ph.data(), want.data(), want.size() * sizeof(Hit)));
+    }
     // bounce rays leaving the hit points, with `start` = the triangle they leave (bvh.rs:329-335)
     std::vector<Ray> bounce;
     std::vector<uint32_t> start;
