@@ -41,3 +41,27 @@ def test_host_cases(exe):
 def test_gpu_cases(exe, tmp_path):
     out = run([exe, "--all", str(tmp_path)])
     assert "triangle::intersection" in out and "scene::load" in out
+
+
+@pytest.mark.gpu
+def test_ptrender_harness(gpu_ctx, tmp_path):
+    """harness/ptrender: scene file in, PNG + PFM out, image equal to what the Python harness renders from the same file."""
+    import numpy as np
+    from pathtracer_amd import core
+    root = os.path.dirname(HERE)
+    exe = os.path.join(root, "harness", "ptrender")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "harness")])
+    scene = os.path.join(root, "examples", "cornell", "scene.toml")
+    out = str(tmp_path / "img")
+    p = subprocess.run([exe, scene, out, "--spp", "4", "--seed", "5"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "rendered 512x512, 4 spp" in p.stdout, p.stdout + p.stderr
+    raw = open(out + ".pfm", "rb").read()
+    assert raw.startswith(b"PF\n512 512\n-1.0\n")
+    pfm = np.frombuffer(raw[len(b"PF\n512 512\n-1.0\n"):], dtype="<f4").reshape(512, 512, 3)[::-1]
+    assert open(out + ".png", "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    s = core.load_scene_file(scene)
+    img = gpu_ctx.render(gpu_ctx.scene(s.arrays), 512, 512, 0, 4, 4, seed=5, sensor_width=s.camera["sensor_width"], focal_length=s.camera["focal_length"])
+    assert np.array_equal(pfm, img[..., :3])
+    bad = subprocess.run([exe, str(tmp_path / "absent.toml"), out], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr
