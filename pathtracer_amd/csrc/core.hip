@@ -332,7 +332,7 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
     }
 
     // ---- Triangle::new (triangle.rs:50-60) ---------------------------------------------------------
-    std::vector<float4> tris((size_t)N * 3u), shade((size_t)N * 5u), boxes(lbvh ? (size_t)N * 2u : 0u);
+    std::vector<float4> tris((size_t)N * 3u), shade((size_t)N * 5u), surf(N), boxes(lbvh ? (size_t)N * 2u : 0u);
     std::atomic<bool> bad_material{false};
     auto precompute = [&](uint32_t begin, uint32_t end) {
     for (uint32_t i = begin; i < end; ++i) {
@@ -346,7 +346,7 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
             boxes[2 * (size_t)i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
             boxes[2 * (size_t)i + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
         }
-        if (t.material_index >= d->n_materials) { bad_material = true; return; }
+        if (t.material_index >= d->n_materials || t.material_index >= (1u << 30)) { bad_material = true; return; }
         float ab[3], ac[3], n[3], n1[3], n2[3], tmp[3];
         for (int k = 0; k < 3; ++k) { ab[k] = t.b[k] - t.a[k]; ac[k] = t.c[k] - t.a[k]; }
         cross3(ab, ac, n);
@@ -364,6 +364,11 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
         float mw, fw;
         const uint32_t flags = t.flags & (PT_TRI_HAS_UV | PT_TRI_HAS_NORMALS);
         std::memcpy(&mw, &t.material_index, 4); std::memcpy(&fw, &flags, 4);
+        // what every scatter needs, in one 16-byte record: Intersection.normal (= n) and material | flags
+        const uint32_t mf = (t.material_index << 2) | flags;
+        float mfw;
+        std::memcpy(&mfw, &mf, 4);
+        surf[i] = make_float4(n[0], n[1], n[2], mfw);
         float4* s = &shade[(size_t)i * 5];
         s[0] = make_float4(mw, fw, t.uv[0][0], t.uv[0][1]);
         s[1] = make_float4(t.uv[1][0], t.uv[1][1], t.uv[2][0], t.uv[2][1]);
@@ -447,6 +452,7 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
         (rc = upload(ctx, s, wide, &s->view.wide, "wide nodes")) != PT_OK ||
         (rc = upload(ctx, s, tris, &s->view.tris, "triangles")) != PT_OK ||
         (rc = upload(ctx, s, shade, &s->view.shade, "shading records")) != PT_OK ||
+        (rc = upload(ctx, s, surf, &s->view.surf, "surface records")) != PT_OK ||
         (rc = upload(ctx, s, mats, &s->view.materials, "materials")) != PT_OK ||
         (rc = upload(ctx, s, images, &s->view.images, "images")) != PT_OK ||
         (rc = upload(ctx, s, texels, &s->view.texels, "texels")) != PT_OK ||

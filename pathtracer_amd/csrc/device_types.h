@@ -32,6 +32,7 @@
 //   w7 = unused (keeps the stride one cache line)
 // ---- triangle intersect record: 48 B = 3 x float4 (triangle.rs:17-24)
 //   t0 = { n.xyz, d }   t1 = { n1.xyz, d1 }   t2 = { n2.xyz, d2 }
+// ---- surface record: 16 B {n.xyz, bits(material << 2 | flags)}: the one gather per scatter of a triangle without uv/normals
 // ---- triangle shading record: 80 B = 5 x float4; the common (no uv, no normals) case reads s0 only
 //   s0 = { bits(material), bits(flags), uv0.x, uv0.y }
 //   s1 = { uv1.x, uv1.y, uv2.x, uv2.y }
@@ -58,6 +59,7 @@ struct DevSceneView {       // passed to kernels by value
     const float4* wide;         // [n_wide][8], see above
     const float4* tris;
     const float4* shade;
+    const float4* surf;         // [n_tris] { n.x, n.y, n.z, bits(material << 2 | flags) }: all a flat-shaded scatter reads
     const DevMaterial* materials;
     const DevImage* images;
     const float* texels;

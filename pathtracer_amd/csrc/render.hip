@@ -140,17 +140,16 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
             const float4 ro = st.rays[2u * p], rd = st.rays[2u * p + 1u];
             const uint2 state = st.state[p];
             const float4* srec = sc.shade + (size_t)tri * 5u;
-            const float4 s0 = srec[0];
-            const float4 t0 = sc.tris[(size_t)tri * 3u];                        // Intersection.normal = tri.n
+            const float4 t0 = sc.surf[tri];                                     // Intersection.normal = tri.n, material | flags
             uint32_t len = state.y & 0xFFu, iter = state.y >> 8;
             float wl[PTC_NW];
             ptc::wavelengths(rd.w, wl);
             const float dist = __uint_as_float(hit.y), hu = __uint_as_float(hit.z), hv = __uint_as_float(hit.w);
-            const uint32_t mat_id = __float_as_uint(s0.x), flags = __float_as_uint(s0.y);
+            const uint32_t mat_id = __float_as_uint(t0.w) >> 2, flags = __float_as_uint(t0.w) & 3u;
             const DevMaterial m = sc.materials[mat_id];
             float u = hu, v = hv;
             if (flags & PT_TRI_HAS_UV) {                                        // material.rs:266-270
-                const float4 s1 = srec[1];
+                const float4 s0 = srec[0], s1 = srec[1];
                 const float w0 = 1.0f - hu - hv;
                 u = w0 * s0.z + hu * s1.x + hv * s1.z;
                 v = w0 * s0.w + hu * s1.y + hv * s1.w;
