@@ -40,9 +40,11 @@ struct PassState {
     float4*   rays;       // [P][2]  {origin.xyz, bits(start triangle)}, {direction.xyz, hero wavelength offset}:
                           //         pt_ray layout with the two pads in use; trace.hip reads the start from pad0
     uint4*    hits;       // [P]
-    uint2*    state;      // [P]  {draws consumed so far by the path's stream, len | iterations << 8}
+    uint2*    state;      // [P]  {draws consumed so far by the path's stream, len (5 bits) | iterations << 5 (11 bits) |
+                          //       emit mask << 16: bit k set = vertex k carries an emission term}
     float4*   verts;      // [P][16][4]: vertex k of path p = {weight[0..3], weight[4..7], emit[0..3], emit[4..7]},
-                          //         one 64-byte line per scatter event, written by one lane
+                          //         one 64-byte line per scatter event, written by one lane; the emit half is only
+                          //         written and read where the state's emit mask says so (7 of 8 soup materials emit nothing)
     uint32_t* queue[2];   // [P] each
     uint32_t* miss_queue; // [P] paths whose ray left the scene; their sky term is evaluated once per pass (k_sky)
     uint32_t* counts;     // [4]: [0..2] rotating live-path counters (iteration i reads [i%3], fills [(i+1)%3],
@@ -55,13 +57,19 @@ __device__ __forceinline__ float4* vert_ptr(const PassState& st, uint32_t p, uin
     return st.verts + ((size_t)p * PTC_MAX_VERTS + k) * 4u;
 }
 __device__ __forceinline__ void store_vertex(const PassState& st, uint32_t p, uint32_t k, const float w[PTC_NW],
-                                             const float e[PTC_NW]) {
+                                             const float e[PTC_NW], bool has_emit) {
     float4* v = vert_ptr(st, p, k);
     v[0] = make_float4(w[0], w[1], w[2], w[3]);
     v[1] = make_float4(w[4], w[5], w[6], w[7]);
-    v[2] = make_float4(e[0], e[1], e[2], e[3]);
-    v[3] = make_float4(e[4], e[5], e[6], e[7]);
+    if (has_emit) {
+        v[2] = make_float4(e[0], e[1], e[2], e[3]);
+        v[3] = make_float4(e[4], e[5], e[6], e[7]);
+    }
 }
+#define PTC_STATE_LEN(y)   ((y) & 0x1Fu)
+#define PTC_STATE_ITER(y)  (((y) >> 5) & 0x7FFu)
+#define PTC_STATE_EMASK(y) ((y) >> 16)
+#define PTC_STATE_PACK(len, iter, emask) ((len) | ((iter) << 5) | ((emask) << 16))
 
 // ---- generate: main.rs:76-89 -----------------------------------------------------------------------
 __global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera cam, uint64_t seed,
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
         const bool missed = active && hit.x == PT_NO_TRIANGLE;
         const bool shading = active && !missed;
 
-        bool cont = false, put_vertex = false, put_dir = false;
+        bool cont = false, put_vertex = false, put_dir = false, has_emit = false;
         float weight[PTC_NW], emit[PTC_NW];
         float4 new_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), new_d = new_o;
         uint2 new_state = make_uint2(0u, 0u);
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
             const uint2 state = st.state[p];
             const float4* srec = sc.shade + (size_t)tri * 5u;
             const float4 t0 = sc.surf[tri];                                     // Intersection.normal = tri.n, material | flags
-            uint32_t len = state.y & 0xFFu, iter = state.y >> 8;
+            uint32_t len = PTC_STATE_LEN(state.y), iter = PTC_STATE_ITER(state.y), emask = PTC_STATE_EMASK(state.y);
             float wl[PTC_NW];
             ptc::wavelengths(rd.w, wl);
             const float dist = __uint_as_float(hit.y), hu = __uint_as_float(hit.z), hv = __uint_as_float(hit.w);
@@ -191,6 +199,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
                     if (i >= 1 && i + 1 < PTC_NW) asm volatile("" : "+v"(wl[i + 1]) : "v"(weight[i - 1]));
                 }
                 if (m.emit_kind == PT_EMIT_ABSORBED_D65) {                      // material.rs:183-185
+                    has_emit = true;
+                    emask |= 1u << len;
                     float ar, ag, ab;
                     ptc::texture_rgb(sc, m.absorb_img, m.absorb, u, v, ar, ag, ab);
 #pragma unroll
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
             iter += 1u;
             // loop header: `for _ in 0..1024` and the capacity check scene.rs:328-331
             cont = cont && (len < PTC_MAX_VERTS) && (iter < PTC_MAX_ITERS);
-            new_state = make_uint2(rng.index, len | (iter << 8));
+            new_state = make_uint2(rng.index, PTC_STATE_PACK(len, iter, emask));
         }
 
         // hand the path on: ballot -> one LDS atomic per wave and list -> slot in the block's buffer
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
         }
 
         if (shading) {
-            if (put_vertex) store_vertex(st, p, vslot, weight, emit);
+            if (put_vertex) store_vertex(st, p, vslot, weight, emit, has_emit);
             if (cont) {
                 st.rays[2u * p] = new_o;
                 if (put_dir) st.rays[2u * p + 1u] = new_d;
@@ -271,14 +281,14 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky
         const uint32_t p = st.miss_queue[k];
         const float4 rd = st.rays[2u * p + 1u];
         const uint2 state = st.state[p];
-        const uint32_t len = state.y & 0xFFu;
+        const uint32_t len = PTC_STATE_LEN(state.y);
         float wl[PTC_NW], e[PTC_NW], zero[PTC_NW];
         ptc::wavelengths(rd.w, wl);
         ptc::evaluate_sky(sc, sky, rd.x, rd.y, rd.z, wl, e);
 #pragma unroll
         for (int i = 0; i < PTC_NW; ++i) zero[i] = 0.0f;
-        store_vertex(st, p, len, zero, e);
-        st.state[p] = make_uint2(state.x, state.y + 1u);
+        store_vertex(st, p, len, zero, e, true);
+        st.state[p] = make_uint2(state.x, (state.y + 1u) | (1u << (16u + len)));       // len + 1, emit bit of the sky vertex
     }
 }
 
@@ -289,14 +299,17 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_accumulate(PassState st, uint32_t
     float4 a = acc[pixel];
     for (uint32_t s = 0; s < spp_pass; ++s) {
         const uint32_t p = s * st.npix + pixel;
-        const uint32_t len = st.state[p].y & 0xFFu;
+        const uint32_t sy = st.state[p].y;
+        const uint32_t len = PTC_STATE_LEN(sy), emask = PTC_STATE_EMASK(sy);
         const float hero = st.rays[2u * p + 1u].w;
         float L[PTC_NW];
 #pragma unroll
         for (int i = 0; i < PTC_NW; ++i) L[i] = 0.0f;
         for (uint32_t k = len; k-- > 0u;) {
             const float4* v = vert_ptr(st, p, k);
-            const float4 w0 = v[0], w1 = v[1], e0 = v[2], e1 = v[3];
+            const float4 w0 = v[0], w1 = v[1];
+            float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0;      // Emit::Null samples to 0 (material.rs:187)
+            if ((emask >> k) & 1u) { e0 = v[2]; e1 = v[3]; }
             L[0] = L[0] * w0.x + e0.x; L[1] = L[1] * w0.y + e0.y; L[2] = L[2] * w0.z + e0.z; L[3] = L[3] * w0.w + e0.w;
             L[4] = L[4] * w1.x + e1.x; L[5] = L[5] * w1.y + e1.y; L[6] = L[6] * w1.z + e1.z; L[7] = L[7] * w1.w + e1.w;
         }
