@@ -26,6 +26,10 @@ int pto_scene_create(const pt_scene_desc* desc, pto_scene** out);
 void pto_scene_destroy(pto_scene* s);
 uint32_t pto_scene_n_nodes(const pto_scene* s);
 void pto_scene_get_nodes(const pto_scene* s, pt_bvh_node* out);
+int pto_triangle_intersect(const float a[3], const float b[3], const float c[3], const float o[3], const float d[3],
+                           float max_distance, float out[6]);
+void pto_camera_ray(uint32_t w, uint32_t h, float sensor_width, float focal, float x, float y, float dir[3]);
+void pto_srgb_to_xyz(const float rgb[3], float out[3]);
 void pto_trace(const pto_scene* sc, const pt_ray* rays, const uint32_t* start, uint64_t n, pt_hit* out,
                uint64_t* counters, int nthreads);
 void pto_render(const pto_scene* sc, const pt_camera* cam, uint32_t spp_begin, uint32_t spp_count, uint32_t spp_total,
@@ -87,6 +91,44 @@ static void camera_corners() {       // camera.rs:47-66
     // centre of the frame looks straight down -Z
     const Ray& mid0 = r[(size_t)(H / 2) * W + W / 2];
     CHECK(std::fabs(mid0.d[0]) <= sx && std::fabs(mid0.d[1]) <= sy);
+}
+
+// the reference's ten unit tests, verbatim, against the CPU oracle: these pin the checker itself
+static void reference_kats_on_the_oracle() {
+    std::printf("oracle: triangle / camera / color KATs\n");
+    const float a[3] = {0, 0, -1}, b[3] = {1, 0, -1}, c[3] = {0, 1, -1}, down[3] = {0, 0, -1}, up[3] = {0, 0, 1};
+    float out[6];
+    {   // triangle.rs:130-148 intersection
+        const float o[3] = {1.0f / 3.0f, 1.0f / 3.0f, 0.0f};
+        CHECK(pto_triangle_intersect(a, b, c, o, down, INFINITY, out) == 1 && out[0] == 1.0f && out[1] == 1.0f / 3.0f && out[2] == 1.0f / 3.0f);
+    }
+    {   // :150-165 miss_t_negative
+        const float a2[3] = {0, 0, 2}, b2[3] = {1, 0, 2}, c2[3] = {0, 1, 2}, o[3] = {2.0f / 3.0f, 2.0f / 3.0f, 0.0f};
+        CHECK(pto_triangle_intersect(a2, b2, c2, o, up, INFINITY, out) == 0);
+    }
+    const float o_uv[3] = {2.0f / 3.0f, 2.0f / 3.0f, 0.0f}, o_u[3] = {-2.0f / 3.0f, 2.0f / 3.0f, 0.0f}, o_v[3] = {2.0f / 3.0f, -2.0f / 3.0f, 0.0f};
+    CHECK(pto_triangle_intersect(a, b, c, o_uv, up, INFINITY, out) == 0);      // :167-182 miss_u_plus_v_greater_than_one
+    CHECK(pto_triangle_intersect(a, b, c, o_u, up, INFINITY, out) == 0);       // :184-199 miss_u_negative
+    CHECK(pto_triangle_intersect(a, b, c, o_v, up, INFINITY, out) == 0);       // :201-216 miss_v_negative
+    // camera.rs:47-66 corners: the expected vectors are normalised, generate_ray's are not (the reference's own test is
+    // stale): compared up to scale
+    const float px[4][2] = {{-0.5f, -0.5f}, {1024.5f, -0.5f}, {-0.5f, 768.5f}, {1024.5f, 768.5f}};
+    const float want[4][3] = {{-18, 13.5f, -50}, {18, 13.5f, -50}, {-18, -13.5f, -50}, {18, -13.5f, -50}};
+    for (int k = 0; k < 4; ++k) {
+        float d[3];
+        pto_camera_ray(1024, 768, 36.0f, 50.0f, px[k][0], px[k][1], d);
+        const float s = d[2] / want[k][2];
+        CHECK(s > 0.0f && std::fabs(d[0] - s * want[k][0]) < 1e-4f && std::fabs(d[1] - s * want[k][1]) < 1e-4f);
+    }
+    // color.rs:184-218 srgb_primary_{r,g,b,w}: chromaticity and luminance within 1e-3
+    const float prim[4][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 1}};
+    const float xyY[4][3] = {{0.64f, 0.33f, 0.2126f}, {0.30f, 0.60f, 0.7152f}, {0.15f, 0.06f, 0.0722f}, {0.3127f, 0.3290f, 1.0f}};
+    for (int k = 0; k < 4; ++k) {
+        float xyz[3];
+        pto_srgb_to_xyz(prim[k], xyz);
+        const float sum = xyz[0] + xyz[1] + xyz[2];
+        CHECK(std::fabs(xyz[0] / sum - xyY[k][0]) < 1e-3f && std::fabs(xyz[1] / sum - xyY[k][1]) < 1e-3f && std::fabs(xyz[1] - xyY[k][2]) < 1e-3f);
+    }
 }
 
 static void bvh_build_matches_the_recursive_restatement() {      // bvh.rs:134-248, 346-356
@@ -258,6 +300,7 @@ int main(int argc, char** argv) {
     const bool host_only = argc > 1 && std::string(argv[1]) == "--host";
     const std::string tmp = argc > 2 ? argv[2] : "/tmp";
     camera_corners();
+    reference_kats_on_the_oracle();
     bvh_build_matches_the_recursive_restatement();
     sky_errors();
     if (!host_only) {
