@@ -44,8 +44,8 @@ int ptc_reserve(pt_ctx* ctx, void** buf, size_t* have, size_t need, const char* 
     if (*buf) { (void)hipFree(*buf); *buf = nullptr; *have = 0; }
     size_t want = need + need / 4;
     hipError_t e = hipMalloc(buf, want);
-    if (e != hipSuccess) { want = need; e = hipMalloc(buf, want); }
-    if (e != hipSuccess) return ptc_hip(ctx, e, what);
+    if (e != hipSuccess) { (void)hipGetLastError(); want = need; e = hipMalloc(buf, want); }
+    if (e != hipSuccess) { (void)hipGetLastError(); *buf = nullptr; return ptc_hip(ctx, e, what); }   // (clears the sticky error: callers may retry smaller)
     *have = want;
     return PT_OK;
 }

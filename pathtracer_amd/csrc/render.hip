@@ -367,23 +367,31 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
     PTC_HIP(ctx, hipSetDevice(ctx->device));
     ctx->stats = pt_stats{};
 
-    // paths per pass: ctx->tune_pass_paths in flight (1 KiB of vertex column each), whole samples only
+    // paths per pass: ctx->tune_pass_paths in flight (1 KiB of vertex column each), whole samples only.  When the
+    // workspace for that does not fit in what is left of HBM the pass is halved until it does (one sample of every
+    // pixel is the floor): smaller passes cost throughput, never the image (samples are independent).
     uint32_t spp_pass = (uint32_t)std::max<uint64_t>(1, (uint64_t)ctx->tune_pass_paths / npix);
     if (spp_pass > spp_count) spp_pass = spp_count ? spp_count : 1u;
-    const uint32_t Pmax = spp_pass * npix;
-
-    // ---- carve the workspace ---------------------------------------------------------------------
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_acc = carve((size_t)npix * sizeof(float4));
-    const size_t o_rays = carve((size_t)Pmax * 2 * sizeof(float4));
-    const size_t o_hits = carve((size_t)Pmax * sizeof(uint4));
-    const size_t o_state = carve((size_t)Pmax * sizeof(uint2));
-    const size_t o_q0 = carve((size_t)Pmax * 4), o_q1 = carve((size_t)Pmax * 4), o_qm = carve((size_t)Pmax * 4);
-    const size_t o_cnt = carve(256);
-    const size_t o_verts = carve((size_t)Pmax * PTC_MAX_VERTS * 2 * PTC_NW * sizeof(float));
-    int rc = ptc_reserve(ctx, &ctx->work, &ctx->work_bytes, off, "render workspace");
-    if (rc != PT_OK) return rc;
+    size_t o_acc, o_rays, o_hits, o_state, o_q0, o_q1, o_qm, o_cnt, o_verts;
+    for (;;) {
+        const uint32_t Pmax = spp_pass * npix;
+        // ---- carve the workspace -----------------------------------------------------------------
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+        o_acc = carve((size_t)npix * sizeof(float4));
+        o_rays = carve((size_t)Pmax * 2 * sizeof(float4));
+        o_hits = carve((size_t)Pmax * sizeof(uint4));
+        o_state = carve((size_t)Pmax * sizeof(uint2));
+        o_q0 = carve((size_t)Pmax * 4); o_q1 = carve((size_t)Pmax * 4); o_qm = carve((size_t)Pmax * 4);
+        o_cnt = carve(256);
+        o_verts = carve((size_t)Pmax * PTC_MAX_VERTS * 2 * PTC_NW * sizeof(float));
+        const int rc = ptc_reserve(ctx, &ctx->work, &ctx->work_bytes, off, "render workspace");
+        if (rc == PT_OK) break;
+        if (rc != PT_ERR_NOMEM || spp_pass == 1u) return rc;
+        spp_pass = (spp_pass + 1u) / 2u;
+    }
+    ctx->error.clear();
+    int rc = PT_OK;
     char* base = (char*)ctx->work;
     float4* acc = (float4*)(base + o_acc);
     PassState st{};

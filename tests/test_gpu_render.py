@@ -184,3 +184,29 @@ def test_sixteen_vertex_cap(oracle, gpu_ctx):
     compare_images(got, want, "closed box", max_diff_frac=0.0, mean_rel=0.0)
     assert st.segments == cnt[1] == 16 * st.paths
     assert np.isfinite(got).all() and got[..., 1].mean() > 0
+
+
+def test_render_halves_its_pass_when_hbm_is_short(gpu_ctx):
+    """With little HBM left the integrator renders in smaller passes instead of failing; the image is the same."""
+    import torch
+    arr = workloads.soup_scene(20_000, sky=workloads.hw_sky())
+    sc = gpu_ctx.scene(arr)
+    w, h, spp = 1920, 1080, 8                                     # one 8-spp pass wants ~18 GB of workspace
+    want = gpu_ctx.render(sc, w, h, 0, spp, spp, seed=2)
+    big = core.Context(0)                                         # a context of its own: its workspace starts empty
+    try:
+        sc2 = big.scene(arr)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info()
+        hog = torch.empty(max(free - (7 << 30), 0), dtype=torch.uint8, device="cuda")      # leave ~7 GB
+        torch.cuda.synchronize()
+        got = big.render(sc2, w, h, 0, spp, spp, seed=2)
+        passes = big.stats().paths // (w * h)
+        assert passes == spp and got.tobytes() == want.tobytes()
+        left, _ = torch.cuda.mem_get_info()
+        assert left < (6 << 30)                                   # it did have to make do with what was left
+        del hog
+    finally:
+        big.close()
+        torch.cuda.empty_cache()
