@@ -228,6 +228,23 @@ private:
     pt_scene* scene_ = nullptr;
 };
 
+// ---- sample-split multi-GPU rendering (one process per GPU) -------------------------------------
+// Rank g renders sample_range(total, g, world) with Scene::render_range (PT_RENDER_SUM: raw XYZ sums, w = samples in
+// the range), the W*H*4 float buffers are summed with one collective (ncclAllReduce / MPI_Allreduce, ncclFloat, sum),
+// and finalize_sums turns the total into the reference's image (main.rs:49,100).  Sample s of pixel p draws from
+// stream (seed, p, s) whatever the split, so the result does not depend on the number of ranks beyond f32 summation order.
+inline std::pair<uint32_t, uint32_t> sample_range(uint32_t spp_total, uint32_t rank, uint32_t world_size) {
+    if (world_size == 0 || rank >= world_size) throw Error(PT_ERR_INVALID, "sample_range: bad rank / world size");
+    const uint32_t base = spp_total / world_size, rem = spp_total % world_size;
+    return {rank * base + (rank < rem ? rank : rem), base + (rank < rem ? 1u : 0u)};       // {begin, count}
+}
+inline void finalize_sums(std::vector<float>& xyzw) {
+    for (size_t p = 0; p + 3 < xyzw.size(); p += 4) {
+        const float inv = 1.0f / xyzw[p + 3];
+        xyzw[p] *= inv; xyzw[p + 1] *= inv; xyzw[p + 2] *= inv; xyzw[p + 3] = 1.0f;
+    }
+}
+
 struct Display {
     std::vector<uint8_t> bgra8;        // what the Bgra8Unorm surface holds (renderer.rs:191)
     float avg_luminance = 0, max_luminance = 0, middle_gray = 0;

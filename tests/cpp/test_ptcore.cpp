@@ -260,6 +260,24 @@ static void traverse_and_render_match_the_oracle(Device& dev) {
         }
     }
     CHECK(bad == 0);
+    // three "ranks" over 4 samples: ranges {0,2},{2,1},{3,1}; summed and finalised = the one-call image up to f32 order
+    std::vector<float> total((size_t)80 * 45 * 4, 0.0f);
+    uint32_t covered = 0;
+    for (uint32_t rank = 0; rank < 3; ++rank) {
+        const auto rg = sample_range(4, rank, 3);
+        CHECK(rg.first == covered);
+        covered += rg.second;
+        const std::vector<float> part = scene.render_range(cam, rg.first, rg.second, 4, 1);
+        for (size_t k = 0; k < total.size(); ++k) total[k] += part[k];
+    }
+    CHECK(covered == 4);
+    finalize_sums(total);
+    size_t off = 0;
+    for (size_t k = 0; k < total.size(); ++k) {
+        const float ref = got_img[k];
+        if (std::isnan(total[k]) != std::isnan(ref) || (!std::isnan(ref) && std::fabs(total[k] - ref) > 1e-5f * std::fabs(ref) + 1e-12f)) ++off;
+    }
+    CHECK(off == 0);
     pto_scene_destroy(o);
 }
 
