@@ -105,6 +105,7 @@ struct pt_ctx {
     uint32_t tune_variant = 1;           // 0: one batch of rays per wave pass, 1: persistent refill
     uint32_t tune_blocks_per_cu = 6;
     uint32_t tune_refill = 16;
+    uint32_t tune_ticket = 64;           // rays a wave reserves per ticket atomic (after its static first block of 64)
     uint32_t tune_shade_blocks_per_cu = 64; // k_shade grid cap (blocks loop over the queue beyond it)
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the persistent traversal kernel
     uint32_t tune_host_chunk = 1u << 20;   // pt_trace_closest: rays per pipelined chunk

@@ -35,9 +35,7 @@
 #ifndef PTC_SHARDS
 #define PTC_SHARDS 8u             /* ticket words / contiguous ray shards per launch (power of two not required) */
 #endif
-#ifndef PTC_TICKET
-#define PTC_TICKET 64u            /* rays a wave reserves per ticket atomic */
-#endif
+#define PTC_FIRST 64u              /* rays of a wave's static first block (one per lane) */
 
 namespace {
 
@@ -245,8 +243,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
 // FAST, persistent form.  Traversal lengths have a heavy tail (soup-1M primaries: mean 51 node
 // visits per ray, but the slowest of 64 neighbouring rays needs 141), so a wave that waits for its
 // slowest lane keeps only ~1/3 of its lanes busy.  Here a lane that finishes its ray takes the next
-// one at once: each wave reserves blocks of 64 consecutive rays from a global ticket counter (one
-// atomic per 64 rays, fetched by lane 0 and broadcast) and hands them to idle lanes by ballot +
+// one at once: each wave reserves blocks of `ticket_size` (64) consecutive rays from a global ticket counter (one
+// atomic per block, fetched by lane 0 and broadcast) and hands them to idle lanes by ballot +
 // popcount rank, whenever at least `refill` lanes are idle.  Lanes only idle during the final drain.
 //
 // WIDE (PT_TRAVERSE_WIDE): the same loop over the two-level records of device_types.h.  A trip tests
@@ -258,7 +256,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
     DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
     uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket,
-    uint32_t* __restrict__ ticket_next, uint32_t refill) {
+    uint32_t* __restrict__ ticket_next, uint32_t refill, uint32_t ticket_size) {
     __shared__ uint2 ring[S * PTC_BLOCK];
     const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -279,7 +277,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
     bool exhausted = false;                    // wave-uniform: the ticket counter ran past n
     bool first_block = true;                   // wave-uniform
     uint32_t shard = blockIdx.x % PTC_SHARDS, shards_done = 0u;                                // wave-uniform
-    const uint32_t shard_len = ((n + PTC_SHARDS * PTC_TICKET - 1u) / (PTC_SHARDS * PTC_TICKET)) * PTC_TICKET;
+    // shard length: a multiple of the static block, so that static and dynamic reservations tile a shard exactly
+    const uint32_t shard_len = ((n + PTC_SHARDS * PTC_FIRST - 1u) / (PTC_SHARDS * PTC_FIRST)) * PTC_FIRST;
     const uint32_t waves_per_label = (gridDim.x / PTC_SHARDS) * (PTC_BLOCK / 64u);            // grid is a multiple of PTC_SHARDS
     bool has_ray = false;
     DRay r = {};
@@ -298,13 +297,14 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                 // A wave's FIRST block is static (its rank among the waves of its label): otherwise every
                 // wave of the grid hits a ticket word at launch, and one word takes only ~90 returning
                 // atomics per microsecond.
-                uint32_t off = 0u;
+                uint32_t off = 0u, size = ticket_size;
                 if (first_block) {
-                    off = ((blockIdx.x / PTC_SHARDS) * (PTC_BLOCK / 64u) + (threadIdx.x >> 6)) * PTC_TICKET;
+                    off = ((blockIdx.x / PTC_SHARDS) * (PTC_BLOCK / 64u) + (threadIdx.x >> 6)) * PTC_FIRST;
+                    size = PTC_FIRST;
                     first_block = false;
                 } else {
-                    if (lane == 0u) off = atomicAdd(ticket + shard * 64u, PTC_TICKET);
-                    off = __builtin_amdgcn_readfirstlane(off) + waves_per_label * PTC_TICKET;
+                    if (lane == 0u) off = atomicAdd(ticket + shard * 64u, ticket_size);
+                    off = __builtin_amdgcn_readfirstlane(off) + waves_per_label * PTC_FIRST;
                 }
                 const uint32_t shard_begin = shard * shard_len;
                 if (off >= shard_len || shard_begin + off >= n) {
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                 } else {
                     const uint32_t shard_end = (n - shard_begin < shard_len) ? n : shard_begin + shard_len;
                     blk_next = shard_begin + off;
-                    blk_end = (shard_end - blk_next < PTC_TICKET) ? shard_end : blk_next + PTC_TICKET;
+                    blk_end = (shard_end - blk_next < size) ? shard_end : blk_next + size;
                 }
             }
             const uint32_t avail = blk_end - blk_next;
@@ -540,8 +540,9 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
         uint32_t* const ticket_next = ctx->ticket + 512u * (ctx->launch_parity ^ 1u);
         ctx->launch_parity ^= 1u;
         const bool q = d_queue != nullptr;
-#define PTC_PERS(SS, W) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, W>), ticket, ticket_next, refill); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, W>), ticket, ticket_next, refill); } while (0)
+#define PTC_PERS(SS, W) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, W>), ticket, ticket_next, refill, tsize); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, W>), ticket, ticket_next, refill, tsize); } while (0)
         const uint32_t refill = ctx->tune_refill < 1u ? 1u : (ctx->tune_refill > 64u ? 64u : ctx->tune_refill);
+        const uint32_t tsize = ctx->tune_ticket < 1u ? 1u : (ctx->tune_ticket > 1024u ? 1024u : ctx->tune_ticket);
         if (ctx->traversal == PT_TRAVERSE_WIDE) {
             switch (ctx->tune_ring) {
                 case 8:  PTC_PERS(8, true); break;
