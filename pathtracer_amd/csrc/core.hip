@@ -284,6 +284,7 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
         const float inf = pt_inf(), nan = std::numeric_limits<float>::quiet_NaN();
         struct Job { uint32_t bin, wide, depth; };
         std::vector<Job> todo;
+        wide.reserve(((size_t)n_internal * 2u / 3u + 16u) * 8u);      // usual count is ~2/3 of the binary nodes; grows if not
         auto new_wide = [&]() { wide.resize(wide.size() + 8u, make_float4(inf, inf, inf, inf)); return (uint32_t)(wide.size() / 8u - 1u); };
         todo.push_back(Job{0u, new_wide(), 1u});
         while (!todo.empty()) {
