@@ -8,10 +8,14 @@
 // One ray per lane, wave64.  The traversal stack is a per-lane SHORT stack in LDS laid out
 // [slot][lane] (8-byte entries, so a wave's push/pop is one conflict-free ds_write_b64 /
 // ds_read_b64); it is a ring: when a lane's ring is full the oldest entry spills to a per-lane
-// column in HBM ([depth][thread], coalesced) and comes back when the ring runs dry.  Nodes are
-// fetched as 4 x 16-byte loads and triangles as 3 x 16-byte loads per lane.
+// column in HBM ([depth][thread], coalesced) and comes back when the ring runs dry.  Binary nodes are
+// fetched as 4 x 16-byte loads, wide nodes as 7, triangles as 3 x 16-byte loads per lane.
 //
-// Two flavours (pt_set_traversal):
+// Three flavours (pt_set_traversal):
+//  WIDE   (default) the FAST rule over two levels of the same tree at a time: the 128-byte records of
+//         device_types.h hold the four grandchildren's boxes (bit for bit the binary nodes' boxes); all four
+//         are tested, sorted by entry distance (ties in binary order), the nearest is entered, the others are
+//         pushed farthest first.  Half as many dependent fetches per ray as FAST.
 //  FAST   near-first DFS with ONE global best distance: a subtree is entered iff best > its entry
 //         distance, a leaf hit replaces the best iff t <= best (so among equal t the later
 //         visited wins, as bvh.rs:299-303).  Visits a subset of what the reference visits and
