@@ -313,14 +313,17 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
             float lo[3][4], hi[3][4];
             // unused slots: a NaN box fails intersects_aabb for every ray (tmax stays NaN, `tmax >= tmin` is false)
             for (int a = 0; a < 3; ++a) for (int k = 0; k < 4; ++k) { lo[a][k] = nan; hi[a][k] = nan; }
-            // children in reverse so that, popped from `todo`, wide nodes come out in preorder
+            // The record holds the children in REVERSE binary order (slot s = child nch-1-s): the kernel's stable sort
+            // then enters boxes of equal entry distance right before left, like the recursion (bvh.rs:266-270).
+            // Wide indices are still handed out in binary order (pushed in reverse, popped from `todo` in preorder).
             for (int k = nch - 1; k >= 0; --k) {
-                if (ch[k].ref & PTC_LEAF_BIT) { refs[k] = ch[k].ref; continue; }
+                const int slot = nch - 1 - k;
+                if (ch[k].ref & PTC_LEAF_BIT) { refs[slot] = ch[k].ref; continue; }
                 const uint32_t wi = new_wide();
-                refs[k] = wi;
+                refs[slot] = wi;
                 todo.push_back(Job{ch[k].ref, wi, j.depth + 1u});
             }
-            for (int k = 0; k < nch; ++k) for (int a = 0; a < 3; ++a) { lo[a][k] = ch[k].lo[a]; hi[a][k] = ch[k].hi[a]; }
+            for (int k = 0; k < nch; ++k) for (int a = 0; a < 3; ++a) { lo[a][nch - 1 - k] = ch[k].lo[a]; hi[a][nch - 1 - k] = ch[k].hi[a]; }
             w = &wide[(size_t)j.wide * 8u];
             for (int a = 0; a < 3; ++a) {
                 w[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);

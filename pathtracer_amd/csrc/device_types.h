@@ -25,7 +25,8 @@
 //   q3 = { r.max.x, r.max.y, r.max.z, 0 }
 // ---- wide node (PT_TRAVERSE_WIDE): 128 B = 8 x float4, two levels of the SAME binary tree collapsed:
 // the children of a wide node are the grandchildren of a binary node (a child that is a leaf stays
-// as it is), in the binary order LL, LR, RL, RR, so every box and every triangle reference is the
+// as it is), stored in REVERSE binary order RR, RL, LR, LL (equal entry distances then resolve right before
+// left, as the recursion does), so every box and every triangle reference is the
 // reference builder's; only the order in which boxes are visited can differ from bvh.rs:265-306.
 //   w0..w2 = min.x, min.y, min.z of children 0..3   w3..w5 = max.x, max.y, max.z of children 0..3
 //   w6 = bits(ref 0..3): leaf bit | triangle, or wide-node index; an empty slot holds a NaN box (never hit)

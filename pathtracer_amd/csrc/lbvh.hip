@@ -202,11 +202,12 @@ __global__ __launch_bounds__(LB_BLOCK) void k_wide(const float4* __restrict__ no
         refs[nch] = (r & PTC_LEAF_BIT) ? r : wide_index[r];
         ++nch;
     };
+    // children in REVERSE binary order (RR, RL, LR, LL), as the host-side collapse stores them (core.hip)
     const float4* q = &nodes[4u * (size_t)i];
-    for (int side = 0; side < 2; ++side) {
+    for (int side = 1; side >= 0; --side) {
         const uint32_t r = __float_as_uint(side ? q[1].w : q[0].w);
         if (r & PTC_LEAF_BIT) take(q, side);
-        else { const float4* q2 = &nodes[4u * (size_t)r]; take(q2, 0); take(q2, 1); }
+        else { const float4* q2 = &nodes[4u * (size_t)r]; take(q2, 1); take(q2, 0); }
     }
     float4* w = &wide[8u * (size_t)wide_index[i]];
     for (int a = 0; a < 3; ++a) {

@@ -359,10 +359,14 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                     const bool h2 = slab_close(bx.t1.x, bx.t2.x, by.t1.x, by.t2.x, bz.t1.x, bz.t2.x, k2) && best_t > k2;
                     const bool h3 = slab_close(bx.t1.y, bx.t2.y, by.t1.y, by.t2.y, bz.t1.y, bz.t2.y, k3) && best_t > k3;
                     k0 = h0 ? k0 : pt_inf(); k1 = h1 ? k1 : pt_inf(); k2 = h2 ? k2 : pt_inf(); k3 = h3 ? k3 : pt_inf();
-                    // 5-exchange sorting network, ascending entry distance (equal keys keep the binary order)
+                    // Ascending entry distance by odd-even transposition: six exchanges of NEIGHBOURS with a strict
+                    // compare, hence stable.  The record holds the children in REVERSE binary order (RR, RL, LR, LL), so
+                    // boxes with equal entry distance are entered right before left, as bvh.rs:266-270 does at every
+                    // binary node (`l_min < r_min` else right first): coincident geometry resolves as in the recursion.
 #define PTC_CSWAP(ka, kb, ra, rb) { const bool sw = ka > kb; const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
                                     const uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
-                    PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k0, k2, r0, r2) PTC_CSWAP(k1, k3, r1, r3) PTC_CSWAP(k1, k2, r1, r2)
+                    PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k1, k2, r1, r2)
+                    PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k1, k2, r1, r2)
 #undef PTC_CSWAP
                     if (k3 < pt_inf()) st.push(ring, r3, __float_as_uint(k3));
                     if (k2 < pt_inf()) st.push(ring, r2, __float_as_uint(k2));

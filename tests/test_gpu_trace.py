@@ -214,3 +214,22 @@ def test_lbvh_rejects_nodes(gpu_ctx):
     h = core.C.c_void_p()
     rc = core.lib().pt_scene_create_ex(gpu_ctx.handle, core.C.byref(d), abi.PT_SCENE_BUILD_LBVH, core.C.byref(h))
     assert rc == abi.PT_ERR_INVALID
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_coincident_triangles_resolve_as_in_the_recursion(oracle, gpu_ctx, mode):
+    """Exactly duplicated triangles (equal boxes, equal t): the reference's recursion enters equal-distance boxes
+    right before left and lets the later hit win (bvh.rs:266-270, 299-303).  Every mode, the 4-wide one included,
+    returns the same triangle of each duplicate cluster as the CPU restatement of that recursion."""
+    rng = np.random.default_rng(11)
+    base = workloads.soup_scene(3000).triangles
+    t = np.concatenate([base, base[rng.integers(0, base.size, 3000)], base[:500], base[:500]])       # clusters of 2..4 copies
+    t = t[rng.permutation(t.size)]
+    arr = abi.SceneArrays(t, core.bvh_build(t), workloads.soup_scene(8).materials, core.sky_d65(1.0))
+    rays = core.gen_primary_rays(256, 144)
+    want = oracle.trace(oracle.scene(arr), rays)
+    assert (want["tri"] != abi.PT_NO_TRIANGLE).mean() > 0.5
+    gpu_ctx.set_traversal(mode)
+    got = gpu_ctx.trace(gpu_ctx.scene(arr), rays)
+    gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
+    assert got.tobytes() == want.tobytes()

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep, GPU against the CPU oracle (GPU box): random scenes (sizes 1..20000, degenerate and
+duplicated triangles, flat and huge/small extents), random rays (axis-parallel directions, origins on box faces,
+zero components), all traversal modes + the device-built BVH, and small renders with random materials
+(dissolve, emitters).  Prints one JSON line; any mismatch beyond an exact equal-t tie is a failure.
+usage: tools/fuzz_parity.py [--seeds N]"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from pathtracer_amd import abi, core, workloads
+from tests.oracle import Oracle
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seeds", type=int, default=40)
+a = ap.parse_args()
+torch.cuda.init()
+ctx, o = core.Context(0), Oracle()
+f32 = np.float32
+stats = {"scenes": 0, "rays": 0, "tie_id_mismatches": {}, "t_mismatches": 0, "images": 0, "pixels_differing": {}, "build_errors_agreed": 0, "failures": []}
+NAMES = {abi.PT_TRAVERSE_WIDE: "wide", abi.PT_TRAVERSE_FAST: "fast", abi.PT_TRAVERSE_EXACT: "exact"}
+
+
+def random_scene(rng):
+    n = int(rng.choice([1, 2, 3, 7, 64, 500, 5000, 20000]))
+    scale = f32(rng.choice([1e-3, 1.0, 1e3]))
+    c = rng.uniform(-1, 1, size=(n, 3)).astype(f32)
+    c[:, 2] -= 3
+    e1, e2 = (rng.uniform(-0.3, 0.3, size=(n, 3)).astype(f32) for _ in range(2))
+    kind = rng.integers(0, 6, size=n)
+    e2[kind == 0] = e1[kind == 0] * f32(2)                  # zero-area (collinear)
+    e1[kind == 1, 2] = 0; e2[kind == 1, 2] = 0              # axis-aligned flat triangles
+    t = np.zeros(n, dtype=abi.TRIANGLE)
+    t["a"], t["b"], t["c"] = c * scale, (c + e1) * scale, (c + e2) * scale
+    dup = kind == 2
+    if dup.sum() > 1:                                        # exact duplicates of one triangle
+        src = np.flatnonzero(dup)[0]
+        for k in "abc":
+            t[k][dup] = t[k][src]
+    t["material_index"] = rng.integers(0, 4, size=n)
+    mats = np.array([abi.default_material(),
+                     abi.flat_material(rng.uniform(0, 1, 3)),
+                     abi.flat_material(rng.uniform(0, 1, 3), emit_rgb=rng.uniform(0, 2, 3)),
+                     abi.flat_material(rng.uniform(0, 1, 3), base_dissolve=float(rng.uniform(0, 1)))], dtype=abi.MATERIAL)
+    sky = workloads.hw_sky() if rng.random() < 0.5 else core.sky_d65(float(rng.uniform(0, 2)))
+    return t, mats, sky, scale
+
+
+def random_rays(rng, n, scale):
+    r = np.zeros(n, dtype=abi.RAY)
+    r["o"] = (rng.uniform(-2, 2, size=(n, 3)) * [1, 1, 1] + [0, 0, 0]).astype(f32) * scale
+    d = rng.normal(size=(n, 3)).astype(f32)
+    kind = rng.integers(0, 5, size=n)
+    d[kind == 0, 0] = 0                                      # zero components: +-inf inverse, NaN slabs
+    d[kind == 1, :2] = 0
+    d[kind == 2] *= f32(1e-6)                                # tiny, un-normalised
+    d[kind == 3] = (np.array([0, 0, -3], dtype=f32) * scale - r["o"][kind == 3])      # aimed at the cloud
+    r["d"] = d
+    return r
+
+
+for seed in range(a.seeds):
+    rng = np.random.default_rng(seed)
+    tris, mats, sky, scale = random_scene(rng)
+    try:
+        nodes = core.bvh_build(tris)
+    except core.PtError as e:
+        try:
+            o.scene(abi.SceneArrays(tris, None, mats, sky))
+            stats["failures"].append(f"seed {seed}: library build failed ({e}) but the oracle built")
+        except Exception:
+            stats["build_errors_agreed"] += 1
+        continue
+    arr = abi.SceneArrays(tris, nodes, mats, sky)
+    osc = o.scene(arr)
+    stats["scenes"] += 1
+    rays = random_rays(rng, 20000, scale)
+    want = o.trace(osc, rays)
+    start = np.where(rng.random(rays.size) < 0.3, want["tri"], abi.PT_NO_TRIANGLE).astype(np.uint32)
+    want_s = o.trace(osc, rays, start)
+    for lbvh in (False, True):
+        if lbvh and tris.size < 2:
+            continue
+        sc = ctx.scene(arr, lbvh=lbvh)
+        for mode in (abi.PT_TRAVERSE_WIDE, abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT):
+            ctx.set_traversal(mode)
+            for got, ref in ((ctx.trace(sc, rays), want), (ctx.trace(sc, rays, start), want_s)):
+                stats["rays"] += rays.size
+                tb = got["t"].view(np.uint32) != ref["t"].view(np.uint32)
+                idm = (got["tri"] != ref["tri"]) & ~tb
+                stats["t_mismatches"] += int(tb.sum())
+                key = ("lbvh/" if lbvh else "reference-tree/") + NAMES[mode]
+                stats["tie_id_mismatches"][key] = stats["tie_id_mismatches"].get(key, 0) + int(idm.sum())
+                if idm.any() and not lbvh and mode == abi.PT_TRAVERSE_EXACT:
+                    i = int(np.flatnonzero(idm)[0])
+                    stats["failures"].append(f"seed {seed} EXACT on the reference tree must reproduce ties too: ray {i} got {got[i]} want {ref[i]}")
+                if tb.any():
+                    i = int(np.flatnonzero(tb)[0])
+                    stats["failures"].append(f"seed {seed} lbvh {lbvh} mode {mode}: ray {i} got {got[i]} want {ref[i]}")
+        ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
+        if seed % 4 == 0:
+            ref = o.render(osc, 48, 32, 0, 4, 4, seed=seed)
+            for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_WIDE):
+                ctx.set_traversal(mode)
+                img = ctx.render(sc, 48, 32, 0, 4, 4, seed=seed)
+                diff = ~((img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))).all(axis=-1)
+                key = ("lbvh/" if lbvh else "reference-tree/") + NAMES[mode]
+                stats["pixels_differing"][key] = stats["pixels_differing"].get(key, 0) + int(diff.sum())
+                if diff.any() and not lbvh and mode == abi.PT_TRAVERSE_EXACT:
+                    stats["failures"].append(f"seed {seed}: EXACT render on the reference tree differs in {int(diff.sum())} pixels")
+            ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
+            stats["images"] += 1
+stats["ok"] = not stats["failures"] and stats["t_mismatches"] == 0
+stats["failures"] = stats["failures"][:10]
+print(json.dumps(stats))
+sys.exit(0 if stats["ok"] else 1)
