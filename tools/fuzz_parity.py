@@ -2,7 +2,7 @@
 """Randomised parity sweep, GPU against the CPU oracle (GPU box): random scenes (sizes 1..20000, degenerate and
 duplicated triangles, flat and huge/small extents), random rays (axis-parallel directions, origins on box faces,
 zero components), all traversal modes + the device-built BVH, and small renders with random materials
-(dissolve, emitters).  Prints one JSON line; any mismatch beyond an exact equal-t tie is a failure.
+(dissolve, emitters, nearest-sampled textures with uv outside [0,1], interpolated vertex normals, random Hosek-Wilkie suns, cameras).  Prints one JSON line; any mismatch beyond an exact equal-t tie is a failure.
 usage: tools/fuzz_parity.py [--seeds N]"""
 import argparse
 import json
@@ -42,13 +42,32 @@ def random_scene(rng):
         src = np.flatnonzero(dup)[0]
         for k in "abc":
             t[k][dup] = t[k][src]
-    t["material_index"] = rng.integers(0, 4, size=n)
+    t["material_index"] = rng.integers(0, 7, size=n)
+    # uv (also outside [0,1]: rem_euclid) and un-normalised vertex normals on random subsets
+    has_uv, has_n = rng.random(n) < 0.5, rng.random(n) < 0.3
+    t["uv"] = rng.uniform(-2, 3, size=(n, 3, 2)).astype(f32)
+    t["vertex_normals"] = rng.normal(size=(n, 3, 3)).astype(f32)
+    t["flags"] = has_uv * abi.PT_TRI_HAS_UV + has_n * abi.PT_TRI_HAS_NORMALS
+    images = [rng.uniform(0, 1, size=(5, 3, 3)).astype(f32), rng.uniform(0, 1, size=(4, 7)).astype(f32),
+              rng.uniform(0, 2, size=(1, 1, 3)).astype(f32)]
+    tex_diffuse, tex_dissolve, tex_emit = abi.default_material(), abi.default_material(), abi.default_material()
+    tex_diffuse["diffuse"]["kind"], tex_diffuse["diffuse"]["image"] = abi.PT_TEX_NEAREST, 0
+    tex_dissolve["dissolve"]["kind"], tex_dissolve["dissolve"]["image"] = abi.PT_TEX_NEAREST, 1
+    tex_dissolve["base_dissolve"] = 0.9
+    tex_emit["emit_kind"] = abi.PT_EMIT_ABSORBED_D65
+    tex_emit["absorption"]["kind"], tex_emit["absorption"]["image"] = abi.PT_TEX_NEAREST, 2
     mats = np.array([abi.default_material(),
                      abi.flat_material(rng.uniform(0, 1, 3)),
                      abi.flat_material(rng.uniform(0, 1, 3), emit_rgb=rng.uniform(0, 2, 3)),
-                     abi.flat_material(rng.uniform(0, 1, 3), base_dissolve=float(rng.uniform(0, 1)))], dtype=abi.MATERIAL)
-    sky = workloads.hw_sky() if rng.random() < 0.5 else core.sky_d65(float(rng.uniform(0, 2)))
-    return t, mats, sky, scale
+                     abi.flat_material(rng.uniform(0, 1, 3), base_dissolve=float(rng.uniform(0, 1))),
+                     tex_diffuse, tex_dissolve, tex_emit], dtype=abi.MATERIAL)
+    if rng.random() < 0.5:
+        sun = rng.normal(size=3)
+        sun[1] = abs(sun[1]) + 0.05                             # above the horizon (scene.rs:121)
+        sky = core.sky_hosek_wilkie(float(rng.uniform(1, 10)), float(rng.uniform(0, 1)), (0, 1, 0), sun / np.linalg.norm(sun))
+    else:
+        sky = core.sky_d65(float(rng.uniform(0, 2)))
+    return t, mats, sky, scale, images
 
 
 def random_rays(rng, n, scale):
@@ -66,17 +85,17 @@ def random_rays(rng, n, scale):
 
 for seed in range(a.seeds):
     rng = np.random.default_rng(seed)
-    tris, mats, sky, scale = random_scene(rng)
+    tris, mats, sky, scale, images = random_scene(rng)
     try:
         nodes = core.bvh_build(tris)
     except core.PtError as e:
         try:
-            o.scene(abi.SceneArrays(tris, None, mats, sky))
+            o.scene(abi.SceneArrays(tris, None, mats, sky, images))
             stats["failures"].append(f"seed {seed}: library build failed ({e}) but the oracle built")
         except Exception:
             stats["build_errors_agreed"] += 1
         continue
-    arr = abi.SceneArrays(tris, nodes, mats, sky)
+    arr = abi.SceneArrays(tris, nodes, mats, sky, images)
     osc = o.scene(arr)
     stats["scenes"] += 1
     rays = random_rays(rng, 20000, scale)
@@ -103,11 +122,12 @@ for seed in range(a.seeds):
                     i = int(np.flatnonzero(tb)[0])
                     stats["failures"].append(f"seed {seed} lbvh {lbvh} mode {mode}: ray {i} got {got[i]} want {ref[i]}")
         ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
-        if seed % 4 == 0:
-            ref = o.render(osc, 48, 32, 0, 4, 4, seed=seed)
+        if seed % 2 == 0:
+            fl, sw = float(rng.uniform(20, 120)), float(rng.uniform(10, 50))
+            ref = o.render(osc, 48, 32, 0, 4, 4, seed=seed, sensor_width=sw, focal_length=fl)
             for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_WIDE):
                 ctx.set_traversal(mode)
-                img = ctx.render(sc, 48, 32, 0, 4, 4, seed=seed)
+                img = ctx.render(sc, 48, 32, 0, 4, 4, seed=seed, sensor_width=sw, focal_length=fl)
                 diff = ~((img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))).all(axis=-1)
                 key = ("lbvh/" if lbvh else "reference-tree/") + NAMES[mode]
                 stats["pixels_differing"][key] = stats["pixels_differing"].get(key, 0) + int(diff.sum())
