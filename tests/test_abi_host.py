@@ -200,3 +200,42 @@ def test_integration_doc_declares_every_entry_point():
     names = sorted(set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr)))
     assert len(names) >= 25
     assert [n for n in names if n not in doc] == []
+
+
+def test_bvh_build_randomised_against_the_recursive_restatement(oracle):
+    """Adversarial inputs for the binned-SAH decisions: centroids in a plane, all at one point (the `extent < EPSILON`
+    halving rule, bvh.rs:171-183), on a coarse grid (many exact ties between buckets), point-sized triangles, three
+    coordinate scales.  The threaded in-place builder must produce the recursive restatement's node vector byte for
+    byte, or fail where it fails (bvh.rs:242)."""
+    f32 = np.float32
+    mats = np.array([abi.default_material()], dtype=abi.MATERIAL)
+    built = errors = 0
+    for seed in range(60):
+        rng = np.random.default_rng(1000 + seed)
+        n = int(rng.choice([1, 2, 3, 4, 5, 9, 33, 257, 1000, 4097]))
+        scale = f32(rng.choice([1e-4, 1.0, 1e4]))
+        c = rng.uniform(-1, 1, size=(n, 3)).astype(f32)
+        if rng.random() < 0.3:
+            c[:, int(rng.integers(0, 3))] = 0
+        if rng.random() < 0.2:
+            c[:] = c[0]
+        if rng.random() < 0.3:
+            c = np.round(c * 4) / 4
+        e1, e2 = (rng.uniform(-0.2, 0.2, size=(n, 3)).astype(f32) for _ in range(2))
+        k = rng.integers(0, 5, size=n)
+        e1[k == 0] = 0
+        e2[k == 0] = 0
+        t = np.zeros(n, dtype=abi.TRIANGLE)
+        t["a"], t["b"], t["c"] = c * scale, (c + e1) * scale, (c + e2) * scale
+        arr = abi.SceneArrays(t, None, mats, core.sky_d65(0.0))
+        try:
+            nodes = core.bvh_build(t)
+        except core.PtError as e:
+            assert e.code == abi.PT_ERR_BVH_DEGENERATE
+            with pytest.raises(Exception):
+                oracle.scene(arr)
+            errors += 1
+            continue
+        assert nodes.tobytes() == oracle.scene(arr).nodes().tobytes(), f"seed {seed}, {n} triangles"
+        built += 1
+    assert built >= 40
