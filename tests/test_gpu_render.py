@@ -210,3 +210,20 @@ def test_render_halves_its_pass_when_hbm_is_short(gpu_ctx):
     finally:
         big.close()
         torch.cuda.empty_cache()
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py on a dozen seeds (the long runs are under profiles/): random degenerate / duplicated geometry,
+    random rays, textures, normals, skies, cameras; every traversal mode on both trees, renders in EXACT and WIDE."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--seeds", "12"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["ok"] and r["scenes"] >= 10 and r["t_mismatches"] == 0
+    assert all(v == 0 for k, v in r["tie_id_mismatches"].items() if k.startswith("reference-tree/"))
+    assert all(v == 0 for k, v in r["pixels_differing"].items() if k.startswith("reference-tree/"))
