@@ -110,7 +110,7 @@ struct pt_ctx {
     uint32_t tune_shade_blocks_per_cu = 64; // k_shade grid cap (blocks loop over the queue beyond it)
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the persistent traversal kernel
     uint32_t tune_host_chunk = 1u << 20;   // pt_trace_closest: rays per pipelined chunk
-    uint32_t tune_pass_paths = 64u << 20; // pt_render: paths in flight per pass (~1.1 KiB of HBM each)
+    uint32_t tune_pass_paths = 128u << 20; // pt_render: paths in flight per pass (~1.1 KiB of HBM each)
 };
 
 int ptc_fail(pt_ctx* ctx, int code, const std::string& msg);
