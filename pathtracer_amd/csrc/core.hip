@@ -107,6 +107,7 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_blocks_per_cu = std::max(1u, std::min(8u, env_u32("PTC_BLOCKS_PER_CU", ctx->tune_blocks_per_cu)));
     ctx->tune_refill = env_u32("PTC_REFILL", ctx->tune_refill);
     ctx->tune_ticket = env_u32("PTC_TICKET", ctx->tune_ticket);
+    ctx->tune_wide_collapse = std::min(2u, env_u32("PTC_WIDE_COLLAPSE", ctx->tune_wide_collapse));
     ctx->tune_shade_blocks_per_cu = std::max(1u, env_u32("PTC_SHADE_BLOCKS_PER_CU", ctx->tune_shade_blocks_per_cu));
     ctx->tune_ring = env_u32("PTC_RING", ctx->tune_ring);
     ctx->tune_host_chunk = std::max(1u << 12, std::min(1u << 28, env_u32("PTC_HOST_CHUNK", ctx->tune_host_chunk)));
@@ -243,6 +244,7 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
     if (!lbvh && N && n_internal != N - 1) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: expected n_triangles-1 internal nodes");
 
     std::vector<float4> nodes((size_t)n_internal * 4u);
+    std::vector<uint32_t> rank_depth(n_internal, 0u);       // depth of internal node by rank (root = 1)
     uint32_t max_depth = 0;
     {
         // depth = internal nodes on the longest root-to-leaf path (bounds the traversal stack)
@@ -258,6 +260,7 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
                 continue;
             }
             if (depth[i] > max_depth) max_depth = depth[i];
+            rank_depth[internal_rank[i]] = depth[i];
             auto ref_of = [&](uint32_t child) -> uint32_t {
                 const pt_bvh_node& c = d->nodes[child];
                 reached[child] = 1;
@@ -278,53 +281,41 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
     if (max_depth > 4096) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_scene_create: BVH deeper than 4096 levels");
 
     // ---- wide nodes: collapse two binary levels into one record (device_types.h) -----------------------
+    // Done on the device after the upload (lbvh.hip: depths, prefix sum, k_wide) unless PTC_WIDE_COLLAPSE says otherwise:
+    // 1 = this host-side loop instead, 2 = both, and the two arrays must be byte-identical (consistency check for tests).
     std::vector<float4> wide;
     uint32_t wide_depth = 0;
-    if (n_internal) {
-        const float inf = pt_inf(), nan = std::numeric_limits<float>::quiet_NaN();
-        struct Job { uint32_t bin, wide, depth; };
-        std::vector<Job> todo;
-        wide.reserve(((size_t)n_internal * 2u / 3u + 16u) * 8u);      // usual count is ~2/3 of the binary nodes; grows if not
-        auto new_wide = [&]() { wide.resize(wide.size() + 8u, make_float4(inf, inf, inf, inf)); return (uint32_t)(wide.size() / 8u - 1u); };
-        todo.push_back(Job{0u, new_wide(), 1u});
-        while (!todo.empty()) {
-            const Job j = todo.back();
-            todo.pop_back();
-            if (j.depth > wide_depth) wide_depth = j.depth;
-            struct Child { float lo[3], hi[3]; uint32_t ref; };
-            Child ch[4];
-            int nch = 0;
-            auto box_of = [&](uint32_t bin, int side, Child& c) {
-                const float4* q = &nodes[(size_t)bin * 4u];
-                const float4 lo = q[side ? 2 : 0], hi = q[side ? 3 : 1];
-                c.lo[0] = lo.x; c.lo[1] = lo.y; c.lo[2] = lo.z; c.hi[0] = hi.x; c.hi[1] = hi.y; c.hi[2] = hi.z;
-                uint32_t r; std::memcpy(&r, side ? &q[1].w : &q[0].w, 4);
-                c.ref = r;
-            };
-            for (int side = 0; side < 2; ++side) {
-                Child c; box_of(j.bin, side, c);
-                if (c.ref & PTC_LEAF_BIT) { ch[nch++] = c; continue; }
-                const uint32_t b2 = c.ref;
-                box_of(b2, 0, ch[nch++]);
-                box_of(b2, 1, ch[nch++]);
-            }
-            uint32_t refs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            float4* w = &wide[(size_t)j.wide * 8u];     // (re-taken after every new_wide(): the vector may move)
+    const uint32_t wide_mode = lbvh ? 0u : ctx->tune_wide_collapse;
+    if (n_internal && wide_mode != 0u) {
+        // wide nodes = internal nodes at odd depth, numbered in node (pre)order; children = the grandchildren (a leaf
+        // child stays), stored in REVERSE binary order: the kernel's stable sort then enters boxes of equal entry
+        // distance right before left, like the recursion (bvh.rs:266-270).  Same rule as k_wide in lbvh.hip.
+        const float nan = std::numeric_limits<float>::quiet_NaN();
+        std::vector<uint32_t> wide_index(n_internal);
+        uint32_t n_wide = 0;
+        for (uint32_t r = 0; r < n_internal; ++r) { wide_index[r] = n_wide; n_wide += rank_depth[r] & 1u; }
+        wide.assign((size_t)n_wide * 8u, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        wide_depth = (max_depth + 1u) / 2u;
+        for (uint32_t r = 0; r < n_internal; ++r) {
+            if (!(rank_depth[r] & 1u)) continue;
             float lo[3][4], hi[3][4];
-            // unused slots: a NaN box fails intersects_aabb for every ray (tmax stays NaN, `tmax >= tmin` is false)
+            uint32_t refs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             for (int a = 0; a < 3; ++a) for (int k = 0; k < 4; ++k) { lo[a][k] = nan; hi[a][k] = nan; }
-            // The record holds the children in REVERSE binary order (slot s = child nch-1-s): the kernel's stable sort
-            // then enters boxes of equal entry distance right before left, like the recursion (bvh.rs:266-270).
-            // Wide indices are still handed out in binary order (pushed in reverse, popped from `todo` in preorder).
-            for (int k = nch - 1; k >= 0; --k) {
-                const int slot = nch - 1 - k;
-                if (ch[k].ref & PTC_LEAF_BIT) { refs[slot] = ch[k].ref; continue; }
-                const uint32_t wi = new_wide();
-                refs[slot] = wi;
-                todo.push_back(Job{ch[k].ref, wi, j.depth + 1u});
+            int nch = 0;
+            auto take = [&](const float4* q, int side) {
+                const float4 l = q[side ? 2 : 0], h = q[side ? 3 : 1];
+                lo[0][nch] = l.x; lo[1][nch] = l.y; lo[2][nch] = l.z; hi[0][nch] = h.x; hi[1][nch] = h.y; hi[2][nch] = h.z;
+                uint32_t ref; std::memcpy(&ref, side ? &q[1].w : &q[0].w, 4);
+                refs[nch] = (ref & PTC_LEAF_BIT) ? ref : wide_index[ref];
+                ++nch;
+            };
+            const float4* q = &nodes[(size_t)r * 4u];
+            for (int side = 1; side >= 0; --side) {
+                uint32_t ref; std::memcpy(&ref, side ? &q[1].w : &q[0].w, 4);
+                if (ref & PTC_LEAF_BIT) take(q, side);
+                else { const float4* q2 = &nodes[(size_t)ref * 4u]; take(q2, 1); take(q2, 0); }
             }
-            for (int k = 0; k < nch; ++k) for (int a = 0; a < 3; ++a) { lo[a][nch - 1 - k] = ch[k].lo[a]; hi[a][nch - 1 - k] = ch[k].hi[a]; }
-            w = &wide[(size_t)j.wide * 8u];
+            float4* w = &wide[(size_t)wide_index[r] * 8u];
             for (int a = 0; a < 3; ++a) {
                 w[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
                 w[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
@@ -332,7 +323,6 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
             float rb[4];
             std::memcpy(rb, refs, 16);
             w[6] = make_float4(rb[0], rb[1], rb[2], rb[3]);
-            w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
 
@@ -470,6 +460,24 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
         return rc;
     }
     ctx->stats = pt_stats{};
+    if (!lbvh && n_internal && wide_mode != 1u) {
+        float4* d_wide = nullptr;
+        uint32_t n_wide = 0, dev_depth = 0, dev_wide_depth = 0;
+        rc = ptc_build_wide_from_nodes(ctx, s->view.nodes, n_internal, &d_wide, &n_wide, &dev_depth, &dev_wide_depth);
+        if (rc != PT_OK) { pt_scene_destroy(ctx, sc.release()); return rc; }
+        s->allocations.push_back(d_wide);
+        bool same = dev_depth == max_depth;
+        if (wide_mode == 2u) {
+            std::vector<float4> back((size_t)n_wide * 8u);
+            same = same && back.size() == wide.size() && dev_wide_depth == wide_depth &&
+                   hipMemcpy(back.data(), d_wide, back.size() * sizeof(float4), hipMemcpyDeviceToHost) == hipSuccess &&
+                   std::memcmp(back.data(), wide.data(), back.size() * sizeof(float4)) == 0;
+        }
+        if (!same) { pt_scene_destroy(ctx, sc.release()); return ptc_fail(ctx, PT_ERR_HIP, "pt_scene_create: device-side wide collapse disagrees with the host's"); }
+        s->view.wide = d_wide;
+        s->info.device_bytes += (size_t)n_wide * 128u;
+        wide_depth = dev_wide_depth;
+    }
     if (lbvh && N >= 2) {
         float4 *d_nodes = nullptr, *d_wide = nullptr;
         uint32_t n_wide = 0;

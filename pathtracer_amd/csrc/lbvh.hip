@@ -218,6 +218,17 @@ __global__ __launch_bounds__(LB_BLOCK) void k_wide(const float4* __restrict__ no
     w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
+// parent links of a finished binary node array (caller-supplied trees: the links are not known yet)
+__global__ __launch_bounds__(LB_BLOCK) void k_parents(const float4* __restrict__ nodes, uint32_t n_internal,
+                                                      uint32_t* __restrict__ parent_of_internal) {
+    const uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (i >= n_internal) return;
+    const uint32_t l = __float_as_uint(nodes[4u * (size_t)i].w), r = __float_as_uint(nodes[4u * (size_t)i + 1u].w);
+    if (!(l & PTC_LEAF_BIT)) parent_of_internal[l] = i;
+    if (!(r & PTC_LEAF_BIT)) parent_of_internal[r] = i;
+    if (i == 0u) parent_of_internal[0] = 0xFFFFFFFFu;
+}
+
 struct Scratch {                     // frees what it holds when the build leaves, however it leaves
     std::vector<void*> p;
     ~Scratch() { for (void* q : p) (void)hipFree(q); }
@@ -319,5 +330,48 @@ int ptc_build_lbvh(pt_ctx* ctx, const float4* h_boxes, uint32_t n, float4** d_no
     *n_wide = nw;
     *d_nodes = nodes; *d_wide = wide;
     own_nodes.p = nullptr; own_wide.p = nullptr;
+    return PT_OK;
+}
+
+
+// The 4-wide records of a binary node array that is already in HBM (the reference-topology tree flattened by
+// pt_scene_create): depths, prefix sum over odd-depth nodes, k_wide — the same kernels the LBVH build ends with, and the
+// same numbering (preorder among wide nodes) and child order as the host-side collapse in core.hip.
+int ptc_build_wide_from_nodes(pt_ctx* ctx, const float4* d_nodes, uint32_t n_internal, float4** d_wide, uint32_t* n_wide,
+                              uint32_t* max_depth, uint32_t* wide_depth) {
+    *d_wide = nullptr;
+    hipStream_t s = ctx->stream;
+    Scratch tmp;
+    uint32_t *par_i = nullptr, *is_wide = nullptr, *wide_index = nullptr, *stats = nullptr;
+    int rc;
+    if ((rc = tmp.get(ctx, &par_i, n_internal, "wide parents")) || (rc = tmp.get(ctx, &is_wide, n_internal, "wide flags")) ||
+        (rc = tmp.get(ctx, &wide_index, n_internal, "wide index")) || (rc = tmp.get(ctx, &stats, 4, "wide stats")))
+        return rc;
+    PTC_HIP(ctx, hipMemsetAsync(stats, 0, 4 * sizeof(uint32_t), s));
+    const uint32_t gi = (n_internal + LB_BLOCK - 1) / LB_BLOCK;
+    hipLaunchKernelGGL(k_parents, dim3(gi), dim3(LB_BLOCK), 0, s, d_nodes, n_internal, par_i);
+    hipLaunchKernelGGL(k_depth, dim3(gi), dim3(LB_BLOCK), 0, s, par_i, n_internal, is_wide, stats);
+    size_t scan_bytes = 0;
+    PTC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_wide, wide_index, (int)n_internal, s));
+    char* scan_tmp = nullptr;
+    if ((rc = tmp.get(ctx, &scan_tmp, scan_bytes, "wide scan workspace"))) return rc;
+    PTC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, is_wide, wide_index, (int)n_internal, s));
+    uint32_t h_last[2] = {0, 0}, h_stats[4] = {0, 0, 0, 0};
+    PTC_HIP(ctx, hipMemcpyAsync(&h_last[0], wide_index + (n_internal - 1u), 4, hipMemcpyDeviceToHost, s));
+    PTC_HIP(ctx, hipMemcpyAsync(&h_last[1], is_wide + (n_internal - 1u), 4, hipMemcpyDeviceToHost, s));
+    PTC_HIP(ctx, hipMemcpyAsync(h_stats, stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+    PTC_HIP(ctx, hipStreamSynchronize(s));
+    const uint32_t nw = h_last[0] + h_last[1];
+    if (nw == 0 || h_stats[0] == 0) return ptc_fail(ctx, PT_ERR_HIP, "wide collapse produced no nodes");
+    float4* wide = nullptr;
+    PTC_HIP(ctx, hipMalloc((void**)&wide, (size_t)nw * 8u * sizeof(float4)));
+    hipLaunchKernelGGL(k_wide, dim3(gi), dim3(LB_BLOCK), 0, s, d_nodes, is_wide, wide_index, n_internal, wide);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(wide); return ptc_hip(ctx, e, "wide collapse"); }
+    *d_wide = wide;
+    *n_wide = nw;
+    *max_depth = h_stats[0];
+    *wide_depth = (h_stats[0] + 1u) / 2u;
     return PT_OK;
 }

@@ -233,3 +233,23 @@ def test_coincident_triangles_resolve_as_in_the_recursion(oracle, gpu_ctx, mode)
     got = gpu_ctx.trace(gpu_ctx.scene(arr), rays)
     gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
     assert got.tobytes() == want.tobytes()
+
+
+def test_device_wide_collapse_is_byte_identical_to_the_host_loop(monkeypatch):
+    """PTC_WIDE_COLLAPSE=2 builds the 4-wide records both ways (device kernels of lbvh.hip, host loop of core.hip) and fails
+    scene creation unless the two arrays are byte-identical and the depths agree."""
+    monkeypatch.setenv("PTC_WIDE_COLLAPSE", "2")
+    ctx = core.Context(0)
+    try:
+        rng = np.random.default_rng(3)
+        for n in (2, 3, 4, 5, 6, 7, 8, 33, 1000, 20_000, 300_000):
+            arr = workloads.soup_scene(n)
+            sc = ctx.scene(arr)
+            assert sc.info().n_internal_nodes == n - 1
+            sc.close()
+        base = workloads.soup_scene(2000).triangles
+        t = np.concatenate([base, base[rng.integers(0, base.size, 2000)]])         # duplicate clusters
+        ctx.scene(abi.SceneArrays(t, core.bvh_build(t), workloads.soup_scene(8).materials, core.sky_d65(1.0))).close()
+        ctx.scene(workloads.box_scene()).close()
+    finally:
+        ctx.close()
