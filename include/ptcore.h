@@ -234,6 +234,12 @@ int pt_set_traversal(pt_ctx* ctx, uint32_t mode);
  *   PT_RENDER_SUM:   xyz = raw sums over the range, w = spp_count  (shard partials; add, then scale) */
 #define PT_RENDER_FINAL 0u
 #define PT_RENDER_SUM   1u
+/* Optional flag, OR-ed into `mode`; an EXTENSION, off by default.  The reference hands evaluate_sky the bounce ray's
+ * direction un-normalised (normal + unit-sphere sample, |d| up to 2: scene.rs:289-292), so under Sky::HosekWilkie
+ * cos(gamma) can exceed 1 and the model's mie term becomes NaN (hosek_wilkie.rs:313-315); most pixels of a sky-lit scene
+ * are then NaN, in the reference as here.  With this flag the direction is normalised (component-wise division by its
+ * norm) before the sky is evaluated; everything else is unchanged. */
+#define PT_RENDER_NORMALIZE_SKY_DIRECTION 0x100u
 int pt_render(pt_ctx* ctx, const pt_scene* scene, const pt_camera* camera, uint32_t spp_begin,
               uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* xyzw);
 int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera* camera, uint32_t spp_begin,

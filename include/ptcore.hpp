@@ -213,6 +213,10 @@ public:
         return render_range(cam, 0, samples, samples, seed, PT_RENDER_FINAL);
     }
     std::vector<float> render(uint64_t seed) const { return render(camera, camera.samples, seed); }
+    // extension: directions normalised before the sky is evaluated (PT_RENDER_NORMALIZE_SKY_DIRECTION, ptcore.h)
+    std::vector<float> render_with_normalised_sky(const Camera& cam, uint32_t samples, uint64_t seed) const {
+        return render_range(cam, 0, samples, samples, seed, PT_RENDER_FINAL | PT_RENDER_NORMALIZE_SKY_DIRECTION);
+    }
     // samples [begin, begin+count) of `total`; PT_RENDER_SUM gives raw sums (w = count) for sharded callers
     std::vector<float> render_range(const Camera& cam, uint32_t begin, uint32_t count, uint32_t total, uint64_t seed,
                                     uint32_t mode = PT_RENDER_SUM) const {

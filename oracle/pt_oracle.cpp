@@ -622,7 +622,7 @@ bool material_sample(const Scene& sc, const pt_material& mat, const Ray& ray, co
     return true;
 }
 
-struct PathCounters { uint64_t segments = 0; Counters trav; };
+struct PathCounters { uint64_t segments = 0; Counters trav; bool normalize_sky = false; /* PT_RENDER_NORMALIZE_SKY_DIRECTION */ };
 
 // scene.rs:307-374
 void radiance(const Scene& sc, Ray ray, const float wl[NW], pt_rng* rng, float out[NW], PathCounters& pc) {
@@ -659,6 +659,10 @@ void radiance(const Scene& sc, Ray ray, const float wl[NW], pt_rng* rng, float o
             }
         } else {                                                                          // :362-367
             float sky[NW];
+            if (pc.normalize_sky) {            // extension (ptcore.h): the reference passes the direction as it is
+                const float n = std::sqrt(dot(ray.direction, ray.direction));
+                evaluate_sky(sc, Ray(ray.origin, {ray.direction.x / n, ray.direction.y / n, ray.direction.z / n}), wl, sky);
+            } else
             evaluate_sky(sc, ray, wl, sky);
             for (int i = 0; i < NW; ++i) { subpath[len].weight[i] = 0.0f; subpath[len].emit[i] = sky[i]; }
             len++;
@@ -945,6 +949,8 @@ void pto_render(const pto_scene* sc, const pt_camera* cam, uint32_t spp_begin, u
     const uint32_t TILE = 32;
     const uint64_t strips = (uint64_t)((H + TILE - 1) / TILE) * W;
     std::vector<PathCounters> pcs((size_t)std::max(1, nthreads));
+    for (auto& p : pcs) p.normalize_sky = (mode & PT_RENDER_NORMALIZE_SKY_DIRECTION) != 0u;
+    mode &= ~PT_RENDER_NORMALIZE_SKY_DIRECTION;
     parallel_for(strips, nthreads, [&](int t, uint64_t b, uint64_t e) {
         for (uint64_t item = b; item < e; ++item) {
             uint32_t x = (uint32_t)(item % W);

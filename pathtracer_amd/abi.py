@@ -31,6 +31,7 @@ PT_RENDER_FINAL = 0
 PT_RENDER_SUM = 1
 PT_TONEMAP_SKIP_NONFINITE = 1
 PT_SCENE_BUILD_LBVH = 1
+PT_RENDER_NORMALIZE_SKY_DIRECTION = 0x100
 
 f4, u4 = np.float32, np.uint32
 

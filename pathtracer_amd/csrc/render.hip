@@ -275,7 +275,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
 }
 
 // ---- sky: Scene::evaluate_sky for every path of the pass that left the scene (scene.rs:362-367) ------
-__global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky* __restrict__ sky, PassState st) {
+__global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky* __restrict__ sky, PassState st, uint32_t normalize) {
     const uint32_t count = st.counts[3];
     for (uint32_t k = blockIdx.x * PTC_BLOCK + threadIdx.x; k < count; k += gridDim.x * PTC_BLOCK) {
         const uint32_t p = st.miss_queue[k];
@@ -284,7 +284,12 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky
         const uint32_t len = PTC_STATE_LEN(state.y);
         float wl[PTC_NW], e[PTC_NW], zero[PTC_NW];
         ptc::wavelengths(rd.w, wl);
-        ptc::evaluate_sky(sc, sky, rd.x, rd.y, rd.z, wl, e);
+        float dx = rd.x, dy = rd.y, dz = rd.z;
+        if (normalize) {                           // PT_RENDER_NORMALIZE_SKY_DIRECTION (extension, ptcore.h)
+            const float n = pt_sqrt(ptc::dot3(dx, dy, dz, dx, dy, dz));
+            dx = dx / n; dy = dy / n; dz = dz / n;
+        }
+        ptc::evaluate_sky(sc, sky, dx, dy, dz, wl, e);
 #pragma unroll
         for (int i = 0; i < PTC_NW; ++i) zero[i] = 0.0f;
         store_vertex(st, p, len, zero, e, true);
@@ -358,6 +363,8 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
                        uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* d_xyzw) {
     if (!scene || !cam || !d_xyzw) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: NULL argument");
     if (cam->width == 0 || cam->height == 0) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: empty image");
+    const uint32_t normalize_sky = mode & PT_RENDER_NORMALIZE_SKY_DIRECTION;
+    mode &= ~PT_RENDER_NORMALIZE_SKY_DIRECTION;
     if (mode != PT_RENDER_FINAL && mode != PT_RENDER_SUM) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: unknown mode");
     if (mode == PT_RENDER_FINAL && spp_total == 0) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render_dev: spp_total is 0");
     const uint64_t npix64 = (uint64_t)cam->width * cam->height;
@@ -454,7 +461,7 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
         // accumulate kernel sees every vertex column complete.
         {
             const uint32_t sky_blocks = std::min<uint32_t>((P + PTC_BLOCK - 1) / PTC_BLOCK, (uint32_t)ctx->n_cus * 16u);
-            hipLaunchKernelGGL(k_sky, dim3(sky_blocks), dim3(PTC_BLOCK), 0, s, scene->view, scene->d_sky, st);
+            hipLaunchKernelGGL(k_sky, dim3(sky_blocks), dim3(PTC_BLOCK), 0, s, scene->view, scene->d_sky, st, normalize_sky);
         }
         hipLaunchKernelGGL(k_accumulate, dim3(pix_blocks), dim3(PTC_BLOCK), 0, s, st, this_spp, acc);
     }

@@ -227,3 +227,19 @@ def test_randomised_parity_sweep():
     assert r["ok"] and r["scenes"] >= 10 and r["t_mismatches"] == 0
     assert all(v == 0 for k, v in r["tie_id_mismatches"].items() if k.startswith("reference-tree/"))
     assert all(v == 0 for k, v in r["pixels_differing"].items() if k.startswith("reference-tree/"))
+
+
+def test_normalised_sky_direction_extension(oracle, gpu_ctx):
+    """PT_RENDER_NORMALIZE_SKY_DIRECTION: off, the Hosek-Wilkie sky sees |d| up to 2 and many pixels are NaN, as in the
+    reference; on, no sample is NaN.  Either way the GPU image equals the CPU restatement's with the same flag."""
+    arr = workloads.soup_scene(20_000, sky=workloads.hw_sky())
+    gsc, osc = gpu_ctx.scene(arr), oracle.scene(arr)
+    flag = abi.PT_RENDER_NORMALIZE_SKY_DIRECTION
+    plain = gpu_ctx.render(gsc, 96, 54, 0, 8, 8, seed=4)
+    fixed = gpu_ctx.render(gsc, 96, 54, 0, 8, 8, seed=4, mode=abi.PT_RENDER_FINAL | flag)
+    want = oracle.render(osc, 96, 54, 0, 8, 8, seed=4, mode=abi.PT_RENDER_FINAL | flag)
+    assert np.isnan(plain).any() and np.isfinite(fixed).all()
+    assert fixed.tobytes() == want.tobytes()
+    part = gpu_ctx.render(gsc, 96, 54, 3, 2, 8, seed=4, mode=abi.PT_RENDER_SUM | flag)
+    assert part.tobytes() == oracle.render(osc, 96, 54, 3, 2, 8, seed=4, mode=abi.PT_RENDER_SUM | flag).tobytes()
+    assert (part[..., 3] == 2.0).all()
