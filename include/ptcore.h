@@ -278,6 +278,15 @@ typedef struct pt_scene_info {
 } pt_scene_info;
 int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out);
 
+/* The scene's binary tree in the form of `BVH.nodes` (bvh.rs:341-343: preorder, root = [0], leaves as entries of
+ * their own) - what the reference holds after BVH::build (bvh.rs:346-356).  For a scene created from the caller's
+ * nodes this returns that vector again (leaf entries with the Node fields zeroed); for PT_SCENE_BUILD_LBVH it hands
+ * the device-built tree to a host that wants it as a `BVH { nodes }` of its own (the reference's traverse_recursive
+ * over it then returns exactly what PT_TRAVERSE_EXACT returns here).  *n_nodes_out = 2 * n_triangles - 1 (0 for
+ * an empty scene); nodes_out == NULL only queries the count; capacity is in entries. */
+int pt_scene_get_bvh(pt_ctx* ctx, const pt_scene* scene, pt_bvh_node* nodes_out, uint32_t capacity,
+                     uint32_t* n_nodes_out);
+
 /* ---- harness helpers (no reference counterpart; synthetic workloads of SURVEY.md §8(d)) --- */
 
 /* "soup" triangle generator: centre ~ U(lo, hi), two edge vectors ~ U([-s, s]^3) with

@@ -195,6 +195,14 @@ public:
 
     const pt_scene* handle() const { return scene_; }
     pt_scene_info info() const { pt_scene_info i{}; pt_scene_get_info(scene_, &i); return i; }
+    // `BVH { nodes }` of this scene (bvh.rs:341-343), also for a tree built on the device
+    std::vector<pt_bvh_node> bvh() const {
+        uint32_t n = 0;
+        dev_->check(pt_scene_get_bvh(dev_->handle(), scene_, nullptr, 0, &n));
+        std::vector<pt_bvh_node> nodes(n);
+        dev_->check(pt_scene_get_bvh(dev_->handle(), scene_, nodes.data(), n, &n));
+        return nodes;
+    }
 
     // self.bvh.traverse(&ray, start, &self.triangles) (scene.rs:333) for a batch; start[i] == PT_NO_TRIANGLE is None
     std::vector<Hit> traverse(const std::vector<Ray>& rays, const std::vector<uint32_t>* start = nullptr) const {

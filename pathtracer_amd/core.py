@@ -53,6 +53,7 @@ def lib():
         "pt_tonemap_dev": (i32, [vp, vp, u32, u32, f32, f32, u32, vp, vp, C.POINTER(f32)]),
         "pt_get_stats": (i32, [vp, C.POINTER(abi.Stats)]),
         "pt_scene_get_info": (i32, [vp, C.POINTER(abi.SceneInfo)]),
+        "pt_scene_get_bvh": (i32, [vp, vp, vp, u32, C.POINTER(u32)]),
         "pt_gen_soup": (i32, [u64, u32, C.POINTER(f32), C.POINTER(f32), f32, f32, u32, vp]),
         "pt_gen_primary_rays": (i32, [C.POINTER(abi.Camera), vp]),
         "pt_host_alloc": (i32, [C.c_size_t, C.POINTER(vp)]),
@@ -75,7 +76,7 @@ EXPORTS = [
     "pt_trace_closest_dev", "pt_set_traversal", "pt_render", "pt_render_dev", "pt_get_stats",
     "pt_scene_get_info", "pt_gen_soup", "pt_gen_primary_rays", "pt_tonemap", "pt_tonemap_dev",
     "pt_scene_file_load", "pt_scene_file_get", "pt_scene_file_free", "pt_scene_create_ex",
-    "pt_host_alloc", "pt_host_free",
+    "pt_host_alloc", "pt_host_free", "pt_scene_get_bvh",
 ]
 
 
@@ -210,6 +211,14 @@ class Scene:
         i = abi.SceneInfo()
         lib().pt_scene_get_info(self.handle, C.byref(i))
         return i
+
+    def bvh(self):
+        """The scene's binary tree as `BVH.nodes` (pt_scene_get_bvh): reference order, also for a device-built tree."""
+        n = C.c_uint32(0)
+        self.ctx._check(lib().pt_scene_get_bvh(self.ctx.handle, self.handle, None, 0, C.byref(n)))
+        nodes = np.zeros(n.value, dtype=abi.BVH_NODE)
+        self.ctx._check(lib().pt_scene_get_bvh(self.ctx.handle, self.handle, abi.ptr(nodes) if n.value else None, n.value, C.byref(n)))
+        return nodes
 
     def close(self):
         if self.handle:

@@ -503,6 +503,54 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
     return PT_OK;
 }
 
+// The scene's binary tree back in the reference's form (enum BVHNode, bvh.rs:123-127, in `BVH.nodes` order: preorder,
+// leaves as entries of their own).  For a scene made from the caller's nodes this is the caller's vector again; for a
+// device-built tree (PT_SCENE_BUILD_LBVH) it is what a host needs to hold that tree as a `BVH { nodes }` of its own.
+extern "C" int pt_scene_get_bvh(pt_ctx* ctx, const pt_scene* scene, pt_bvh_node* nodes_out, uint32_t capacity,
+                                uint32_t* n_nodes_out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!scene || !n_nodes_out) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_get_bvh: NULL argument");
+    const uint32_t N = scene->view.n_tris;
+    const uint32_t total = N ? 2u * N - 1u : 0u;
+    *n_nodes_out = total;
+    if (!nodes_out) return PT_OK;                    // size query
+    if (capacity < total) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_get_bvh: nodes_out holds fewer than 2 * n_triangles - 1 entries");
+    if (total == 0) return PT_OK;
+    PTC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<float4> dev;
+    try { dev.resize((size_t)(N - 1u) * 4u); } catch (const std::bad_alloc&) { return ptc_fail(ctx, PT_ERR_NOMEM, "pt_scene_get_bvh: out of host memory"); }
+    if (N > 1u) PTC_HIP(ctx, hipMemcpy(dev.data(), scene->view.nodes, dev.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    struct Item { uint32_t ref, parent; bool right; };
+    std::vector<Item> todo;
+    todo.push_back({scene->view.root_ref, 0xFFFFFFFFu, false});
+    uint32_t count = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (count == total) return ptc_fail(ctx, PT_ERR_HIP, "pt_scene_get_bvh: the device tree is not a tree over the scene's triangles");
+        const uint32_t idx = count++;
+        pt_bvh_node& o = nodes_out[idx];
+        std::memset(&o, 0, sizeof(o));
+        if (it.parent != 0xFFFFFFFFu) (it.right ? nodes_out[it.parent].child_r_index : nodes_out[it.parent].child_l_index) = idx;
+        if (it.ref & PTC_LEAF_BIT) {
+            o.is_leaf = 1u;
+            o.shape_index = it.ref & PTC_INDEX_MASK;
+            continue;
+        }
+        if (it.ref >= N - 1u) return ptc_fail(ctx, PT_ERR_HIP, "pt_scene_get_bvh: node reference out of range");
+        const float4* q = &dev[(size_t)it.ref * 4u];
+        o.child_l_aabb = pt_aabb{{q[0].x, q[0].y, q[0].z}, {q[1].x, q[1].y, q[1].z}};
+        o.child_r_aabb = pt_aabb{{q[2].x, q[2].y, q[2].z}, {q[3].x, q[3].y, q[3].z}};
+        uint32_t lref, rref;
+        std::memcpy(&lref, &q[0].w, 4);
+        std::memcpy(&rref, &q[1].w, 4);
+        todo.push_back({rref, idx, true});
+        todo.push_back({lref, idx, false});           // popped first: parent, left subtree, right subtree (bvh.rs:163-164)
+    }
+    if (count != total) return ptc_fail(ctx, PT_ERR_HIP, "pt_scene_get_bvh: the device tree is not a tree over the scene's triangles");
+    return PT_OK;
+}
+
 // ---- seam 2: closest hit ------------------------------------------------------------------------------
 
 extern "C" int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,

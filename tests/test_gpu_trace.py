@@ -253,3 +253,40 @@ def test_device_wide_collapse_is_byte_identical_to_the_host_loop(monkeypatch):
         ctx.scene(workloads.box_scene()).close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("n_tris", [0, 1, 2, 7, 20_000])
+def test_scene_bvh_round_trip_of_caller_nodes(gpu_ctx, n_tris):
+    """pt_scene_get_bvh undoes the flattening of pt_scene_create: the caller's `BVH.nodes` come back (Node fields of leaf
+    entries zeroed, as pt_bvh_build leaves them)."""
+    arr = workloads.soup_scene(n_tris) if n_tris else workloads.empty_scene()
+    back = gpu_ctx.scene(arr).bvh()
+    want = arr.nodes if arr.nodes is not None else np.zeros(0, dtype=abi.BVH_NODE)
+    assert back.size == max(2 * n_tris - 1, 0) and back.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 64, 20_000, 300_000])
+def test_device_built_tree_is_a_reference_tree(oracle, gpu_ctx, n_tris):
+    """The device-built tree, read back as `BVH.nodes`, is a tree the reference's own recursion can walk: the CPU
+    restatement of traverse_recursive over it returns what the GPU returns, bit for bit - ids at ties included in EXACT
+    mode, and in FAST / WIDE as well on these scenes - and creating a scene from the read-back nodes gives the same tree
+    again."""
+    arr = workloads.soup_scene(n_tris)
+    gsc = gpu_ctx.scene(arr, lbvh=True)
+    nodes = gsc.bvh()
+    assert nodes.size == 2 * n_tris - 1 and int(nodes["is_leaf"].sum()) == n_tris
+    assert np.array_equal(np.sort(nodes["shape_index"][nodes["is_leaf"] == 1]), np.arange(n_tris))
+    arr2 = abi.SceneArrays(arr.triangles, nodes, arr.materials, arr.sky, arr.images)
+    osc = oracle.scene(arr2)
+    rays = core.gen_primary_rays(320, 180)
+    want = oracle.trace(osc, rays)
+    start = np.where(np.arange(rays.size) % 3 == 0, want["tri"], abi.PT_NO_TRIANGLE).astype(np.uint32)
+    want_s = oracle.trace(osc, rays, start)
+    try:
+        for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_WIDE):
+            gpu_ctx.set_traversal(mode)
+            assert gpu_ctx.trace(gsc, rays).tobytes() == want.tobytes(), mode
+            assert gpu_ctx.trace(gsc, rays, start).tobytes() == want_s.tobytes(), mode
+    finally:
+        gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
+    assert gpu_ctx.scene(arr2).bvh().tobytes() == nodes.tobytes()
