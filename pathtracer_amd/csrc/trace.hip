@@ -26,6 +26,8 @@
 //         result = first_distance < second_distance ? first : second (bvh.rs:299-303).  Frames
 //         live on the same LDS ring: an "A" frame {far ref, far tmin} waits for the near result,
 //         a "B" frame {first id | tag, first distance} waits for the far result.
+// FAST, WIDE and EXACT run as persistent kernels that hand the next ray to a lane as soon as it is done
+// (RayTickets); PTC_TRACE_VARIANT=0 selects the older one-batch-per-wave kernels of FAST and EXACT.
 //
 // All float arithmetic is written in the reference's operation order and the file is compiled
 // with -ffp-contract=off: no FMA, IEEE division, minNum/maxNum for f32::min/max.
@@ -175,6 +177,61 @@ __device__ __forceinline__ void load_node(const float4* nodes, uint32_t idx, flo
     q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
 }
 
+// ---- dynamic ray reservation of the persistent kernels (wave-uniform state) ---------------------
+// The batch is cut into PTC_SHARDS contiguous shards, each with its own ticket word; a wave works on the shard
+// of its block label (blockIdx % PTC_SHARDS: blocks with the same label tend to share an XCD, hence an L2) and
+// moves on to the next shard when its own runs dry.  A wave's FIRST block is static (its rank among the waves
+// of its label): otherwise every wave of the grid hits a ticket word at launch, and one word takes only ~90
+// returning atomics per microsecond.
+struct RayTickets {
+    uint32_t blk_next, blk_end;      // unassigned part of the reserved block
+    uint32_t shard, shards_done, shard_len, waves_per_label;
+    bool exhausted;                  // every shard's counter ran past its end
+    bool first_block;
+
+    __device__ __forceinline__ void init(uint32_t n) {
+        blk_next = blk_end = 0u;
+        exhausted = false;
+        first_block = true;
+        shard = blockIdx.x % PTC_SHARDS;
+        shards_done = 0u;
+        // shard length: a multiple of the static block, so that static and dynamic reservations tile a shard exactly
+        shard_len = ((n + PTC_SHARDS * PTC_FIRST - 1u) / (PTC_SHARDS * PTC_FIRST)) * PTC_FIRST;
+        waves_per_label = (gridDim.x / PTC_SHARDS) * (PTC_BLOCK / 64u);            // grid is a multiple of PTC_SHARDS
+    }
+    // Hands the next rays to the wave's idle lanes (ballot `idle`, `n_idle` of them): true and the batch position
+    // `k` for a lane that got one.  Reserves further blocks of `ticket_size` rays as needed.
+    __device__ __forceinline__ bool take(unsigned long long idle, uint32_t n_idle, uint32_t lane, bool lane_idle, uint32_t n,
+                                         uint32_t* __restrict__ ticket, uint32_t ticket_size, uint32_t& k) {
+        while (blk_next == blk_end && !exhausted) {
+            uint32_t off = 0u, size = ticket_size;
+            if (first_block) {
+                off = ((blockIdx.x / PTC_SHARDS) * (PTC_BLOCK / 64u) + (threadIdx.x >> 6)) * PTC_FIRST;
+                size = PTC_FIRST;
+                first_block = false;
+            } else {
+                if (lane == 0u) off = atomicAdd(ticket + shard * 64u, ticket_size);
+                off = __builtin_amdgcn_readfirstlane(off) + waves_per_label * PTC_FIRST;
+            }
+            const uint32_t shard_begin = shard * shard_len;
+            if (off >= shard_len || shard_begin + off >= n) {
+                shards_done += 1u;
+                if (shards_done == PTC_SHARDS) { exhausted = true; blk_next = blk_end = 0u; }
+                else shard = (shard + 1u == PTC_SHARDS) ? 0u : shard + 1u;
+            } else {
+                const uint32_t shard_end = (n - shard_begin < shard_len) ? n : shard_begin + shard_len;
+                blk_next = shard_begin + off;
+                blk_end = (shard_end - blk_next < size) ? shard_end : blk_next + size;
+            }
+        }
+        const uint32_t avail = blk_end - blk_next;
+        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        k = blk_next + rank;
+        blk_next += (n_idle < avail) ? n_idle : avail;
+        return lane_idle && rank < avail;
+    }
+};
+
 #define PTC_IDLE 0xFFFFFFFFu   /* "needs a pop": leaf bit set, never a valid triangle index */
 
 // FAST.  Every loop iteration runs three predicated phases, so a lane can visit a node, test the
@@ -277,13 +334,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
         return;
     }
 
-    uint32_t blk_next = 0u, blk_end = 0u;     // wave-uniform: unassigned part of the reserved block
-    bool exhausted = false;                    // wave-uniform: the ticket counter ran past n
-    bool first_block = true;                   // wave-uniform
-    uint32_t shard = blockIdx.x % PTC_SHARDS, shards_done = 0u;                                // wave-uniform
-    // shard length: a multiple of the static block, so that static and dynamic reservations tile a shard exactly
-    const uint32_t shard_len = ((n + PTC_SHARDS * PTC_FIRST - 1u) / (PTC_SHARDS * PTC_FIRST)) * PTC_FIRST;
-    const uint32_t waves_per_label = (gridDim.x / PTC_SHARDS) * (PTC_BLOCK / 64u);            // grid is a multiple of PTC_SHARDS
+    RayTickets tk;
+    tk.init(n);
     bool has_ray = false;
     DRay r = {};
     uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE;
@@ -293,38 +345,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
         // ---- refill ----
         const unsigned long long idle = __ballot(!has_ray);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (!exhausted && (n_idle >= refill || n_idle == 64u)) {
-            while (blk_next == blk_end && !exhausted) {
-                // The batch is cut into PTC_SHARDS contiguous shards, each with its own ticket word; a wave
-                // works on the shard of its block label (blockIdx % PTC_SHARDS: blocks with the same label
-                // tend to share an XCD, hence an L2) and moves on to the next shard when its own runs dry.
-                // A wave's FIRST block is static (its rank among the waves of its label): otherwise every
-                // wave of the grid hits a ticket word at launch, and one word takes only ~90 returning
-                // atomics per microsecond.
-                uint32_t off = 0u, size = ticket_size;
-                if (first_block) {
-                    off = ((blockIdx.x / PTC_SHARDS) * (PTC_BLOCK / 64u) + (threadIdx.x >> 6)) * PTC_FIRST;
-                    size = PTC_FIRST;
-                    first_block = false;
-                } else {
-                    if (lane == 0u) off = atomicAdd(ticket + shard * 64u, ticket_size);
-                    off = __builtin_amdgcn_readfirstlane(off) + waves_per_label * PTC_FIRST;
-                }
-                const uint32_t shard_begin = shard * shard_len;
-                if (off >= shard_len || shard_begin + off >= n) {
-                    shards_done += 1u;
-                    if (shards_done == PTC_SHARDS) { exhausted = true; blk_next = blk_end = 0u; }
-                    else shard = (shard + 1u == PTC_SHARDS) ? 0u : shard + 1u;
-                } else {
-                    const uint32_t shard_end = (n - shard_begin < shard_len) ? n : shard_begin + shard_len;
-                    blk_next = shard_begin + off;
-                    blk_end = (shard_end - blk_next < size) ? shard_end : blk_next + size;
-                }
-            }
-            const uint32_t avail = blk_end - blk_next;
-            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!has_ray && rank < avail) {
-                const uint32_t k = blk_next + rank;
+        if (!tk.exhausted && (n_idle >= refill || n_idle == 64u)) {
+            uint32_t k;
+            if (tk.take(idle, n_idle, lane, !has_ray, n, ticket, ticket_size, k)) {
                 ray_i = QUEUED ? queue[k] : k;
                 const float4 ro = rays[2 * (size_t)ray_i];
                 r = make_ray(ro, rays[2 * (size_t)ray_i + 1]);
@@ -335,10 +358,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                 cur = sc.root_ref;
                 has_ray = true;
             }
-            blk_next += (n_idle < avail) ? n_idle : avail;
         }
         if (__ballot(has_ray) == 0ull) {
-            if (exhausted) break;
+            if (tk.exhausted) break;
             continue;                      // block ran dry mid-refill: reserve another one
         }
         if (has_ray) {
@@ -508,6 +530,121 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, cons
     }
 }
 
+// EXACT, persistent form: the same frames, with the ray reservation of the FAST kernel (a lane whose recursion has
+// returned takes the next ray at once) and the three phases per trip (node step, leaf, returns).
+template <int S, bool QUEUED>
+__global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact_persistent(
+    DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
+    const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
+    uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket,
+    uint32_t* __restrict__ ticket_next, uint32_t refill, uint32_t ticket_size) {
+    __shared__ uint2 ring[S * PTC_BLOCK];
+    const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (count_ptr) n = *count_ptr;
+    if (gtid < PTC_SHARDS) ticket_next[gtid * 64u] = 0u;      // see k_trace_fast_persistent
+    LaneStack<S> st;
+    st.spill = spill + gtid;
+    st.spill_stride = total_threads;
+    st.reset();
+    if (sc.n_tris == 0u) {          // empty BVH: every ray misses (bvh.rs:364-368)
+        for (uint32_t k = gtid; k < n; k += total_threads) out[QUEUED ? queue[k] : k] = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
+        return;
+    }
+    RayTickets tk;
+    tk.init(n);
+    bool has_ray = false, descending = false;
+    DRay r = {};
+    uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = 0u;
+    uint32_t ret_id = PTC_NONE_ID;       // value being returned up the (virtual) call stack: None = {NONE_ID, +inf}
+    float ret_t = pt_inf();
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!has_ray);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!tk.exhausted && (n_idle >= refill || n_idle == 64u)) {
+            uint32_t k;
+            if (tk.take(idle, n_idle, lane, !has_ray, n, ticket, ticket_size, k)) {
+                ray_i = QUEUED ? queue[k] : k;
+                const float4 ro = rays[2 * (size_t)ray_i];
+                r = make_ray(ro, rays[2 * (size_t)ray_i + 1]);
+                skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[ray_i] : PT_NO_TRIANGLE);
+                ret_id = PTC_NONE_ID; ret_t = pt_inf();
+                st.reset();
+                cur = sc.root_ref;
+                descending = true;
+                has_ray = true;
+            }
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (tk.exhausted) break;
+            continue;
+        }
+        if (has_ray) {
+            // ---- phase 1: internal node (bvh.rs:259-325) ----
+            if (descending && !(cur & PTC_LEAF_BIT)) {
+                float4 q0, q1, q2, q3;
+                load_node(sc.nodes, cur, q0, q1, q2, q3);
+                float lt, rt;
+                const bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);
+                const bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);
+                const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
+                const bool left_first = lt < rt;                              // bvh.rs:266
+                // A frame: far ref (tag bit clear) + far entry distance
+                if (lh && rh) st.push(ring, left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
+                cur = (lh && (left_first || !rh)) ? lref : rref;             // bvh.rs:264-323
+                if (!(lh || rh)) { ret_id = PTC_NONE_ID; ret_t = pt_inf(); descending = false; }   // bvh.rs:324
+            }
+            // ---- phase 2: leaf (bvh.rs:327-336) ----
+            if (descending && (cur & PTC_LEAF_BIT)) {
+                const uint32_t tri = cur & PTC_INDEX_MASK;
+                ret_id = PTC_NONE_ID; ret_t = pt_inf();
+                if (tri != skip) {
+                    const float4* tp = sc.tris + (size_t)tri * 3u;
+                    float d, u, v;
+                    if (tri_test(r, tp[0], tp[1], tp[2], d, u, v)) { ret_id = tri; ret_t = d; }
+                }
+                descending = false;
+            }
+            // ---- phase 3: return through the frames until one sends the lane down again ----
+            while (!descending) {
+                if (st.empty()) {
+                    uint4 o = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
+                    if (ret_id != PTC_NONE_ID) {
+                        // u, v of the winner: the same arithmetic on the same inputs gives the same bits
+                        const float4* tp = sc.tris + (size_t)ret_id * 3u;
+                        float d, u, v;
+                        tri_test(r, tp[0], tp[1], tp[2], d, u, v);
+                        o = make_uint4(ret_id, __float_as_uint(d), __float_as_uint(u), __float_as_uint(v));
+                    }
+                    out[ray_i] = o;
+                    has_ray = false;
+                    break;
+                }
+                const uint2 e = st.pop(ring);
+                const bool is_b = ((e.x & PTC_FRAME_BIT) != 0u) && ((e.x & PTC_LEAF_BIT) == 0u);
+                if (!is_b) {
+                    // near subtree returned `ret`; bvh.rs:280-285
+                    const float first_distance = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
+                    if (first_distance > __uint_as_float(e.y)) {
+                        st.push(ring, PTC_FRAME_BIT | ret_id, __float_as_uint(ret_t));   // B frame keeps `first`
+                        cur = e.x;
+                        descending = true;
+                    }
+                    // else: return first_intersection unchanged (bvh.rs:304-306)
+                } else {
+                    // far subtree returned `ret`; bvh.rs:294-303
+                    const uint32_t f_id = e.x & PTC_INDEX_MASK;
+                    const float f_t = __uint_as_float(e.y);
+                    const float fd = (f_id != PTC_NONE_ID) ? f_t : pt_inf();
+                    const float sd = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
+                    if (fd < sd) { ret_id = f_id; ret_t = f_t; }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Leaf refs carry PTC_LEAF_BIT with PTC_FRAME_BIT clear (indices < 2^30), internal refs have both
@@ -537,7 +674,7 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
     uint2* spill = reinterpret_cast<uint2*>(ctx->spill);
     dim3 grid(blocks), block(PTC_BLOCK);
 #define PTC_LAUNCH(kern, ...) hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, v, rays, d_start, d_queue, d_count, n, out, spill, total_threads, ##__VA_ARGS__)
-    if (ctx->traversal == PT_TRAVERSE_EXACT) {
+    if (ctx->traversal == PT_TRAVERSE_EXACT && ctx->tune_variant == 0) {
         if (d_queue) PTC_LAUNCH((k_trace_exact<S, true>));
         else PTC_LAUNCH((k_trace_exact<S, false>));
     } else if (ctx->tune_variant == 0 && ctx->traversal != PT_TRAVERSE_WIDE) {
@@ -551,7 +688,10 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
 #define PTC_PERS(SS, W) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, W>), ticket, ticket_next, refill, tsize); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, W>), ticket, ticket_next, refill, tsize); } while (0)
         const uint32_t refill = ctx->tune_refill < 1u ? 1u : (ctx->tune_refill > 64u ? 64u : ctx->tune_refill);
         const uint32_t tsize = ctx->tune_ticket < 1u ? 1u : (ctx->tune_ticket > 1024u ? 1024u : ctx->tune_ticket);
-        if (ctx->traversal == PT_TRAVERSE_WIDE) {
+        if (ctx->traversal == PT_TRAVERSE_EXACT) {
+            if (q) PTC_LAUNCH((k_trace_exact_persistent<12, true>), ticket, ticket_next, refill, tsize);
+            else PTC_LAUNCH((k_trace_exact_persistent<12, false>), ticket, ticket_next, refill, tsize);
+        } else if (ctx->traversal == PT_TRAVERSE_WIDE) {
             switch (ctx->tune_ring) {
                 case 8:  PTC_PERS(8, true); break;
                 case 10: PTC_PERS(10, true); break;

@@ -217,6 +217,24 @@ static void traverse_and_render_match_the_oracle(Device& dev) {
         CHECK(same_bits(got.data(), want.data(), got.size() * sizeof(Hit)));
     }
     dev.set_traversal(PT_TRAVERSE_DEFAULT);
+    {   // the scene hands its tree back as `BVH.nodes`; a tree built on the device is one the recursion can walk
+        const std::vector<pt_bvh_node> back = scene.bvh();
+        CHECK(back.size() == b.nodes.size() && same_bits(back.data(), b.nodes.data(), back.size() * sizeof(pt_bvh_node)));
+        const Scene on_device = Scene::with_device_bvh(dev, t, m, sky);
+        BVH db;
+        db.nodes = on_device.bvh();
+        CHECK(db.nodes.size() == 2 * t.size() - 1);
+        pt_scene_desc dd = desc_of(t, db, m, sky);
+        pto_scene* od = nullptr;
+        CHECK(pto_scene_create(&dd, &od) == PT_OK);
+        std::vector<Hit> want_d(rays.size());
+        pto_trace(od, rays.data(), nullptr, rays.size(), want_d.data(), nullptr, 8);
+        dev.set_traversal(PT_TRAVERSE_EXACT);
+        const std::vector<Hit> got_d = on_device.traverse(rays);
+        dev.set_traversal(PT_TRAVERSE_DEFAULT);
+        CHECK(same_bits(got_d.data(), want_d.data(), got_d.size() * sizeof(Hit)));
+        pto_scene_destroy(od);
+    }
     size_t n_hit = 0;
     for (const Hit& h : want) n_hit += h.tri != PT_NO_TRIANGLE;
     CHECK(n_hit > rays.size() / 4);
