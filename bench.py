@@ -229,14 +229,28 @@ def main():
                      "active_lanes_per_valu_instruction": (tj["SQ_THREAD_CYCLES_VALU"] / tj["SQ_INSTS_VALU"]) if tj.get("SQ_THREAD_CYCLES_VALU") else None,
                      "wave_cycles_waiting_frac": (tj["SQ_WAIT_ANY"] / tj["SQ_WAVE_CYCLES"]) if tj.get("SQ_WAVE_CYCLES") else None,
                      "note": "instruction counts from profiles/traffic.json (rocprofv3 --pmc), time measured live; 2.4 GHz assumed"}
+        l1 = None
+        gpath = os.path.join(ROOT, "profiles", "gather_roof.json")
+        if traffic is not None and tj.get("TCP_TOTAL_CACHE_ACCESSES_sum") and os.path.exists(gpath):
+            # third view, same profile: the vector L1's access path.  TCP_TOTAL_CACHE_ACCESSES counts one access per
+            # active lane of a dwordx4 load (calibrated on harness/ptgather, whose lane-load count is known); the ceiling
+            # is what that program reaches when every lane walks its own chain of L1-resident 128-byte records.
+            gj = json.load(open(gpath))
+            l1 = {"bound": "vector-L1 accesses", "accesses_per_launch": tj["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                  "achieved": tj["TCP_TOTAL_CACHE_ACCESSES_sum"] / (kernel_ms_avg * 1e-3) / 1e9, "peak": gj["l1_lane_loads_per_ns"],
+                  "unit": "lane-loads/ns", "frac": tj["TCP_TOTAL_CACHE_ACCESSES_sum"] / (kernel_ms_avg * 1e-3) / 1e9 / gj["l1_lane_loads_per_ns"],
+                  "l1_miss_lines_per_ns": (tj["TCP_TCC_READ_REQ_sum"] / (kernel_ms_avg * 1e-3) / 1e9) if tj.get("TCP_TCC_READ_REQ_sum") else None,
+                  "random_line_ceiling_per_ns": gj.get("random_lines_per_ns"),
+                  "note": "ceilings measured on this GPU model by harness/ptgather (" + gj.get("source", "profiles/") + ")"}
         roofline = {
-            "bound": "hbm", "kernel": "k_trace_exact" if a.traversal == "exact" else f"k_trace_fast_persistent ({a.traversal})",
+            "bound": "hbm", "kernel": "k_trace_exact_persistent" if a.traversal == "exact" else f"k_trace_fast_persistent ({a.traversal})",
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
             "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_ray": b_ray, "n_node": n_node, "n_tri": n_tri, "visit_counts": counts_src,
             "kernel_ms": kernel_ms_avg,
             "algorithmic_bytes_per_launch": b_ray * n,
             "issue_side": issue,
+            "l1_side": l1,
             "note": "achieved = algorithmic bytes (B_ray = 32 + 16 + 64*n_node + 48*n_tri under the REFERENCE's traversal "
                     "rule, SURVEY.md 8d) / kernel time. The ~100 MB node+triangle set is re-read from L1/L2/Infinity Cache, "
                     "so measured HBM-side traffic is a small fraction of the algorithmic bytes and the kernel is bound by "

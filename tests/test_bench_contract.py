@@ -1,5 +1,5 @@
 """The JSON line bench.py prints (driver contract): checked on the committed output of the last GPU run
-(profiles/r01h_bench.json is what `python bench.py` printed on the MI355X box) and on bench.py's own source."""
+(profiles/r01i_bench.json is what `python bench.py` printed on the MI355X box) and on bench.py's own source."""
 import json
 import os
 import re
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_key():
-    j = json.load(open(os.path.join(ROOT, "profiles", "r01h_bench.json")))
+    j = json.load(open(os.path.join(ROOT, "profiles", "r01i_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k

@@ -44,7 +44,7 @@ if "FETCH_SIZE" in means:
     }
     # issue side (SQ counters; *_CYCLES and ACTIVE_INST_* are in quad-cycles per SIMD-wave slot, summed over the chip)
     for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_THREAD_CYCLES_VALU",
-              "SQ_WAVES", "GRBM_GUI_ACTIVE", "TA_BUSY_avr", "TCP_TCP_LATENCY_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCC_READ_REQ_sum"):
+              "SQ_WAVES", "GRBM_GUI_ACTIVE", "TA_BUSY_avr", "TCP_TCP_LATENCY_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"):
         if c in means:
             t[c] = means[c]
     # MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B and reads exactly half of the
