@@ -134,6 +134,8 @@ for seed in range(a.first_seed, a.first_seed + a.seeds):
             tree_osc, tree_want, tree_want_s = osc, want, want_s
         for mode in (abi.PT_TRAVERSE_WIDE, abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT):
             ctx.set_traversal(mode)
+            if tris.size >= 100000:
+                print(f"  lbvh {lbvh} mode {NAMES[mode]}", file=sys.stderr, flush=True)      # big scenes: keep the log moving
             for got, ref in ((ctx.trace(sc, rays), tree_want), (ctx.trace(sc, rays, start), tree_want_s)):
                 stats["rays"] += rays.size
                 key0 = "lbvh/" if lbvh else "reference-tree/"
