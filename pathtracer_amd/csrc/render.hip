@@ -42,9 +42,11 @@ struct PassState {
     uint4*    hits;       // [P]
     uint2*    state;      // [P]  {draws consumed so far by the path's stream, len (5 bits) | iterations << 5 (11 bits) |
                           //       emit mask << 16: bit k set = vertex k carries an emission term}
-    float4*   verts;      // [P][16][4]: vertex k of path p = {weight[0..3], weight[4..7], emit[0..3], emit[4..7]},
-                          //         one 64-byte line per scatter event, written by one lane; the emit half is only
-                          //         written and read where the state's emit mask says so (7 of 8 soup materials emit nothing)
+    float4*   verts;      // weights [16][P][2] then emits [16][P][2]: vertex k of path p = {weight[0..3], weight[4..7]} and
+                          //         {emit[0..3], emit[4..7]}, vertex-major so that the lanes of an iteration (k_shade) and the
+                          //         neighbouring pixels of a sample (k_accumulate) touch neighbouring 32-byte records; the emit
+                          //         record is only written and read where the state's emit mask says so (7 of 8 soup materials
+                          //         emit nothing)
     uint32_t* queue[2];   // [P] each
     uint32_t* miss_queue; // [P] paths whose ray left the scene; their sky term is evaluated once per pass (k_sky)
     uint32_t* counts;     // [4]: [0..2] rotating live-path counters (iteration i reads [i%3], fills [(i+1)%3],
@@ -53,17 +55,21 @@ struct PassState {
     uint32_t  npix;
 };
 
-__device__ __forceinline__ float4* vert_ptr(const PassState& st, uint32_t p, uint32_t k) {
-    return st.verts + ((size_t)p * PTC_MAX_VERTS + k) * 4u;
+__device__ __forceinline__ float4* weight_ptr(const PassState& st, uint32_t p, uint32_t k) {
+    return st.verts + ((size_t)k * st.P + p) * 2u;
+}
+__device__ __forceinline__ float4* emit_ptr(const PassState& st, uint32_t p, uint32_t k) {
+    return st.verts + ((size_t)(PTC_MAX_VERTS + k) * st.P + p) * 2u;
 }
 __device__ __forceinline__ void store_vertex(const PassState& st, uint32_t p, uint32_t k, const float w[PTC_NW],
                                              const float e[PTC_NW], bool has_emit) {
-    float4* v = vert_ptr(st, p, k);
+    float4* v = weight_ptr(st, p, k);
     v[0] = make_float4(w[0], w[1], w[2], w[3]);
     v[1] = make_float4(w[4], w[5], w[6], w[7]);
     if (has_emit) {
-        v[2] = make_float4(e[0], e[1], e[2], e[3]);
-        v[3] = make_float4(e[4], e[5], e[6], e[7]);
+        float4* ev = emit_ptr(st, p, k);
+        ev[0] = make_float4(e[0], e[1], e[2], e[3]);
+        ev[1] = make_float4(e[4], e[5], e[6], e[7]);
     }
 }
 #define PTC_STATE_LEN(y)   ((y) & 0x1Fu)
@@ -311,10 +317,10 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_accumulate(PassState st, uint32_t
 #pragma unroll
         for (int i = 0; i < PTC_NW; ++i) L[i] = 0.0f;
         for (uint32_t k = len; k-- > 0u;) {
-            const float4* v = vert_ptr(st, p, k);
+            const float4* v = weight_ptr(st, p, k);
             const float4 w0 = v[0], w1 = v[1];
             float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0;      // Emit::Null samples to 0 (material.rs:187)
-            if ((emask >> k) & 1u) { e0 = v[2]; e1 = v[3]; }
+            if ((emask >> k) & 1u) { const float4* ev = emit_ptr(st, p, k); e0 = ev[0]; e1 = ev[1]; }
             L[0] = L[0] * w0.x + e0.x; L[1] = L[1] * w0.y + e0.y; L[2] = L[2] * w0.z + e0.z; L[3] = L[3] * w0.w + e0.w;
             L[4] = L[4] * w1.x + e1.x; L[5] = L[5] * w1.y + e1.y; L[6] = L[6] * w1.z + e1.z; L[7] = L[7] * w1.w + e1.w;
         }
