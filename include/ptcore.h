@@ -191,8 +191,9 @@ int  pt_scene_create(pt_ctx* ctx, const pt_scene_desc* desc, pt_scene** out);
  * in the reference, whose BVH::build is a host recursion): desc->nodes must be NULL.  LBVH — 63-bit Morton
  * order of the triangle boxes' centres, Karras radix tree, boxes fitted bottom-up — so the TOPOLOGY differs
  * from BVH::build: every pt_trace_closest / pt_render result is still the minimum-t hit over the same
- * triangles with the same arithmetic, only exact equal-t ties can resolve differently, and traversal visits
- * more nodes than in the SAH tree.  pt_get_stats().total_ms afterwards = device time of the build. */
+ * triangles with the same arithmetic, only exact equal-t ties (and hits within rounding of each other, see
+ * pt_set_traversal) can resolve differently, and traversal visits more nodes than in the SAH tree.
+ * pt_scene_get_bvh returns the tree in the reference's own form.  pt_get_stats().total_ms afterwards = device time of the build. */
 #define PT_SCENE_BUILD_LBVH 1u
 int  pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* desc, uint32_t flags, pt_scene** out);
 void pt_scene_destroy(pt_ctx* ctx, pt_scene* scene);
@@ -215,14 +216,17 @@ int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_ray
                          const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out);
 
 /* Traversal flavour used by both calls above and by pt_render.  All three walk the caller's BVH (same
- * boxes, same triangles, same arithmetic per box and per triangle) and return the same minimum-t hit. */
-#define PT_TRAVERSE_FAST  0u  /* binary nodes, global-best pruning; same hit as the reference except on
-                                 exact equal-t ties                                    */
+ * boxes, same triangles, same arithmetic per box and per triangle).  EXACT returns what
+ * traverse_recursive returns, on every ray.  FAST and WIDE return the minimum-t hit; they can name another
+ * triangle than the recursion where two hits tie exactly or lie within about 2 ulp of each other (a box's
+ * entry distance and the distance of the triangle inside it are rounded independently, and these two prune
+ * against the best hit of the whole ray where the recursion prunes against the sibling's): 2 rays of
+ * 678 M in the randomised sweep, none on the benchmark scenes. */
+#define PT_TRAVERSE_FAST  0u  /* binary nodes, global-best pruning                                 */
 #define PT_TRAVERSE_EXACT 1u  /* replays traverse_recursive's local pruning and tie rules
-                                 (bvh.rs:265-306) frame by frame                                   */
+                                 (bvh.rs:265-306) frame by frame; about 0.43 of WIDE's rate        */
 #define PT_TRAVERSE_WIDE  2u  /* two levels of the same tree per step (4 boxes at once, nearest first,
-                                 global-best pruning); as FAST, only an exact equal-t tie can pick
-                                 another triangle                                                  */
+                                 global-best pruning)                                              */
 #define PT_TRAVERSE_DEFAULT PT_TRAVERSE_WIDE
 int pt_set_traversal(pt_ctx* ctx, uint32_t mode);
 

@@ -19,8 +19,10 @@
 //  FAST   near-first DFS with ONE global best distance: a subtree is entered iff best > its entry
 //         distance, a leaf hit replaces the best iff t <= best (so among equal t the later
 //         visited wins, as bvh.rs:299-303).  Visits a subset of what the reference visits and
-//         returns the same minimum-t hit; only exact equal-t ties / hits exactly at a pruned
-//         box's entry distance can pick a different triangle.
+//         returns the same minimum-t hit; only exact equal-t ties / hits at a pruned box's entry
+//         distance - or, by rounding, up to 2 ulp before it: a box's entry distance and the distance
+//         of the triangle inside it are rounded independently - can pick a different triangle
+//         (2 rays of 678 M in the randomised sweep).
 //  EXACT  replays the recursion frame by frame: the far child of a node is entered iff the NEAR
 //         SUBTREE's own result is farther than the far box (bvh.rs:285), no global pruning,
 //         result = first_distance < second_distance ? first : second (bvh.rs:299-303).  Frames
