@@ -217,11 +217,11 @@ int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_ray
 
 /* Traversal flavour used by both calls above and by pt_render.  All three walk the caller's BVH (same
  * boxes, same triangles, same arithmetic per box and per triangle).  EXACT returns what
- * traverse_recursive returns, on every ray.  FAST and WIDE return the minimum-t hit; they can name another
- * triangle than the recursion where two hits tie exactly or lie within about 2 ulp of each other (a box's
- * entry distance and the distance of the triangle inside it are rounded independently, and these two prune
- * against the best hit of the whole ray where the recursion prunes against the sibling's): 2 rays of
- * 678 M in the randomised sweep, none on the benchmark scenes. */
+ * traverse_recursive returns, on every ray.  FAST and WIDE return the minimum-t hit, pruning against the best
+ * hit of the whole ray (strictly only against hits found in the near sibling's subtree, as the recursion
+ * compares); they can name another triangle than the recursion only where two hits tie exactly or lie within
+ * about 2 ulp of each other, in arrangements that rule does not cover: about one ray in 10^8 on scenes
+ * built to provoke it, none on the benchmark scenes. */
 #define PT_TRAVERSE_FAST  0u  /* binary nodes, global-best pruning                                 */
 #define PT_TRAVERSE_EXACT 1u  /* replays traverse_recursive's local pruning and tie rules
                                  (bvh.rs:265-306) frame by frame; about 0.43 of WIDE's rate        */

@@ -19,10 +19,10 @@
 //  FAST   near-first DFS with ONE global best distance: a subtree is entered iff best > its entry
 //         distance, a leaf hit replaces the best iff t <= best (so among equal t the later
 //         visited wins, as bvh.rs:299-303).  Visits a subset of what the reference visits and
-//         returns the same minimum-t hit; only exact equal-t ties / hits at a pruned box's entry
-//         distance - or, by rounding, up to 2 ulp before it: a box's entry distance and the distance
-//         of the triangle inside it are rounded independently - can pick a different triangle
-//         (2 rays of 678 M in the randomised sweep).
+//         returns the same minimum-t hit.  The comparison with a box is strict only against a hit
+//         found in the near sibling's subtree (ptc_worth_entering below), which keeps equal-t ties and
+//         hits a rounding error apart with the recursion in all but about one ray in 10^8 of the
+//         randomised sweep.
 //  EXACT  replays the recursion frame by frame: the far child of a node is entered iff the NEAR
 //         SUBTREE's own result is farther than the far box (bvh.rs:285), no global pruning,
 //         result = first_distance < second_distance ? first : second (bvh.rs:299-303).  Frames
@@ -236,6 +236,20 @@ struct RayTickets {
 
 #define PTC_IDLE 0xFFFFFFFFu   /* "needs a pop": leaf bit set, never a valid triangle index */
 
+// FAST / WIDE pruning rule.  The recursion never compares a box with a hit from ANOTHER subtree: it enters every box
+// the ray meets, and skips the far child only if the near child's own result is not farther than the far box
+// (`first.distance > far_min`, strict, bvh.rs:285).  These kernels prune against the best hit of the whole ray, which
+// in exact arithmetic loses nothing; to stay with the recursion where distances are EQUAL (coplanar triangles, flat
+// boxes entered exactly at the triangle's t) the comparison is strict only when the best hit was found after the
+// entry was pushed - i.e. inside the near sibling's subtree, the one case in which the recursion compares at all - and
+// non-strict otherwise.  The parity of the number of accepted hits travels with every stack entry for that, in bit 30
+// of the reference (free outside EXACT); `tagbit` is that parity, kept in place.  Distances are non-negative, so
+// their bit patterns order like the floats and "strict" is "one less": enter iff bits(best) - changed >= bits(entry).
+__device__ __forceinline__ bool ptc_worth_entering(uint2 e, float best_t, uint32_t tagbit) {
+    const uint32_t changed = ((e.x ^ tagbit) >> 30) & 1u;
+    return (int32_t)(__float_as_uint(best_t) - changed) >= (int32_t)e.y;
+}
+
 // FAST.  Every loop iteration runs three predicated phases, so a lane can visit a node, test the
 // leaf it descends into and pop its next subtree in ONE trip; the wave's trip count is then about
 // the largest per-lane node count instead of the sum of node, leaf and pop steps.
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
         // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
         const uint32_t skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[i] : PT_NO_TRIANGLE);
         float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
-        uint32_t best_id = PT_NO_TRIANGLE;
+        uint32_t best_id = PT_NO_TRIANGLE, tagbit = 0u;
         st.reset();
         uint32_t cur = sc.root_ref;
         bool alive = sc.n_tris != 0u;
@@ -272,11 +286,11 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
                 float lt, rt;
                 bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);    // bvh.rs:260
                 bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);    // bvh.rs:261
-                lh = lh && (best_t > lt);
-                rh = rh && (best_t > rt);
+                lh = lh && (best_t >= lt);
+                rh = rh && (best_t >= rt);
                 const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
                 const bool left_first = lt < rt;                              // bvh.rs:266
-                if (lh && rh) st.push(ring, left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
+                if (lh && rh) st.push(ring, (left_first ? rref : lref) | tagbit, __float_as_uint(left_first ? rt : lt));
                 cur = (lh && (left_first || !rh)) ? lref : (rh ? rref : PTC_IDLE);
             }
             // ---- phase 2: leaf (bvh.rs:327-336) ----
@@ -287,6 +301,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
                     float d, u, v;
                     if (tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
                         best_t = d; best_u = u; best_v = v; best_id = tri;
+                        tagbit ^= PTC_FRAME_BIT;
                     }
                 }
                 cur = PTC_IDLE;
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const
             while (cur == PTC_IDLE) {
                 if (st.empty()) { alive = false; break; }
                 const uint2 e = st.pop(ring);
-                if (best_t > __uint_as_float(e.y)) cur = e.x;
+                if (ptc_worth_entering(e, best_t, tagbit)) cur = e.x & ~PTC_FRAME_BIT;
             }
         }
         out[i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
     tk.init(n);
     bool has_ray = false;
     DRay r = {};
-    uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE;
+    uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE, tagbit = 0u;
     float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
 
     for (;;) {
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                 // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
                 skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[ray_i] : PT_NO_TRIANGLE);
                 best_t = pt_inf(); best_u = 0.0f; best_v = 0.0f; best_id = PT_NO_TRIANGLE;
+                tagbit = 0u;
                 st.reset();
                 cur = sc.root_ref;
                 has_ray = true;
@@ -378,10 +394,10 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                     const PairF ax = slab_axis2(lox.x, lox.y, hix.x, hix.y, r.ox, r.ix), bx = slab_axis2(lox.z, lox.w, hix.z, hix.w, r.ox, r.ix);
                     const PairF ay = slab_axis2(loy.x, loy.y, hiy.x, hiy.y, r.oy, r.iy), by = slab_axis2(loy.z, loy.w, hiy.z, hiy.w, r.oy, r.iy);
                     const PairF az = slab_axis2(loz.x, loz.y, hiz.x, hiz.y, r.oz, r.iz), bz = slab_axis2(loz.z, loz.w, hiz.z, hiz.w, r.oz, r.iz);
-                    const bool h0 = slab_close(ax.t1.x, ax.t2.x, ay.t1.x, ay.t2.x, az.t1.x, az.t2.x, k0) && best_t > k0;
-                    const bool h1 = slab_close(ax.t1.y, ax.t2.y, ay.t1.y, ay.t2.y, az.t1.y, az.t2.y, k1) && best_t > k1;
-                    const bool h2 = slab_close(bx.t1.x, bx.t2.x, by.t1.x, by.t2.x, bz.t1.x, bz.t2.x, k2) && best_t > k2;
-                    const bool h3 = slab_close(bx.t1.y, bx.t2.y, by.t1.y, by.t2.y, bz.t1.y, bz.t2.y, k3) && best_t > k3;
+                    const bool h0 = slab_close(ax.t1.x, ax.t2.x, ay.t1.x, ay.t2.x, az.t1.x, az.t2.x, k0) && best_t >= k0;
+                    const bool h1 = slab_close(ax.t1.y, ax.t2.y, ay.t1.y, ay.t2.y, az.t1.y, az.t2.y, k1) && best_t >= k1;
+                    const bool h2 = slab_close(bx.t1.x, bx.t2.x, by.t1.x, by.t2.x, bz.t1.x, bz.t2.x, k2) && best_t >= k2;
+                    const bool h3 = slab_close(bx.t1.y, bx.t2.y, by.t1.y, by.t2.y, bz.t1.y, bz.t2.y, k3) && best_t >= k3;
                     k0 = h0 ? k0 : pt_inf(); k1 = h1 ? k1 : pt_inf(); k2 = h2 ? k2 : pt_inf(); k3 = h3 ? k3 : pt_inf();
                     // Ascending entry distance by odd-even transposition: six exchanges of NEIGHBOURS with a strict
                     // compare, hence stable.  The record holds the children in REVERSE binary order (RR, RL, LR, LL), so
@@ -392,9 +408,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                     PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k1, k2, r1, r2)
                     PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k1, k2, r1, r2)
 #undef PTC_CSWAP
-                    if (k3 < pt_inf()) st.push(ring, r3, __float_as_uint(k3));
-                    if (k2 < pt_inf()) st.push(ring, r2, __float_as_uint(k2));
-                    if (k1 < pt_inf()) st.push(ring, r1, __float_as_uint(k1));
+                    if (k3 < pt_inf()) st.push(ring, r3 | tagbit, __float_as_uint(k3));
+                    if (k2 < pt_inf()) st.push(ring, r2 | tagbit, __float_as_uint(k2));
+                    if (k1 < pt_inf()) st.push(ring, r1 | tagbit, __float_as_uint(k1));
                     cur = (k0 < pt_inf()) ? r0 : PTC_IDLE;
                 } else {
                     float4 q0, q1, q2, q3;
@@ -402,11 +418,11 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                     float lt, rt;
                     bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);
                     bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);
-                    lh = lh && (best_t > lt);
-                    rh = rh && (best_t > rt);
+                    lh = lh && (best_t >= lt);
+                    rh = rh && (best_t >= rt);
                     const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
                     const bool left_first = lt < rt;                              // bvh.rs:266
-                    if (lh && rh) st.push(ring, left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
+                    if (lh && rh) st.push(ring, (left_first ? rref : lref) | tagbit, __float_as_uint(left_first ? rt : lt));
                     cur = (lh && (left_first || !rh)) ? lref : (rh ? rref : PTC_IDLE);
                 }
             }
@@ -418,6 +434,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                     float d, u, v;
                     if (tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
                         best_t = d; best_u = u; best_v = v; best_id = tri;
+                        tagbit ^= PTC_FRAME_BIT;
                     }
                 }
                 cur = PTC_IDLE;
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                     break;
                 }
                 const uint2 e = st.pop(ring);
-                if (best_t > __uint_as_float(e.y)) cur = e.x;
+                if (ptc_worth_entering(e, best_t, tagbit)) cur = e.x & ~PTC_FRAME_BIT;
             }
         }
     }

@@ -292,15 +292,16 @@ def test_device_built_tree_is_a_reference_tree(oracle, gpu_ctx, n_tris):
     assert gpu_ctx.scene(arr2).bvh().tobytes() == nodes.tobytes()
 
 
-def test_the_two_rays_where_the_default_traversal_parts_from_the_recursion(oracle, gpu_ctx):
-    """The randomised sweep's two instructive rays, kept as they were found.  EXACT returns the recursion's
-    answer on both.  Seed 910, ray 18391: a flat axis-aligned triangle whose box is entered (by rounding) 2 ulp after
-    the triangle's own t, and a hit from another subtree inside that gap: FAST and WIDE, pruning against the best hit of
-    the whole ray, return the hit 2 ulp farther.  Seed 1912, ray 14942: two coplanar triangles hit at the same t under
-    different children of one binary node: WIDE, entering the four grandchildren by their own entry distances, keeps
-    the other one of the tie; FAST keeps the recursion's."""
+def test_the_sweeps_instructive_rays(oracle, gpu_ctx):
+    """Two rays the randomised sweep found, kept as they were found.  EXACT returns the recursion's answer
+    on both.  Seed 910, ray 18391: a flat axis-aligned triangle whose box is entered (by rounding) exactly at the t of
+    a hit in ANOTHER subtree, 2 ulp after the triangle's own t.  A kernel that prunes `best > entry` against the best
+    hit of the whole ray loses it (FAST and WIDE did, until the comparison became non-strict for hits found before the
+    entry was pushed - trace.hip: ptc_worth_entering); the recursion, which only ever compares siblings, does not.
+    Seed 1912, ray 14942: two coplanar triangles hit at the same t under different children of one binary node: WIDE,
+    entering the four grandchildren by their own entry distances, keeps the other one of the tie; FAST keeps the
+    recursion's."""
     from tests import fuzz_scenes
-    got = {}
     for seed, ray in ((910, 18391), (1912, 14942)):
         rng = np.random.default_rng(seed)
         tris, mats, sky, scale, images = fuzz_scenes.random_scene(rng)
@@ -308,21 +309,20 @@ def test_the_two_rays_where_the_default_traversal_parts_from_the_recursion(oracl
         rays = fuzz_scenes.random_rays(rng, 20000, scale)
         want = oracle.trace(oracle.scene(arr), rays)
         gsc = gpu_ctx.scene(arr)
+        got = {}
         try:
             for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_WIDE):
                 gpu_ctx.set_traversal(mode)
                 hits = gpu_ctx.trace(gsc, rays)
                 others = np.arange(rays.size) != ray
                 assert hits[others].tobytes() == want[others].tobytes(), (seed, mode)
-                got[seed, mode] = hits[ray]
+                got[mode] = hits[ray]
         finally:
             gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
-        assert got[seed, abi.PT_TRAVERSE_EXACT].tobytes() == want[ray].tobytes()
-        ulps = {m: int(got[seed, m]["t"].view(np.int32)) - int(want[ray]["t"].view(np.int32)) for m in (abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_WIDE)}
+        assert got[abi.PT_TRAVERSE_EXACT].tobytes() == want[ray].tobytes()
+        assert got[abi.PT_TRAVERSE_FAST].tobytes() == want[ray].tobytes()
         if seed == 910:
-            assert ulps == {abi.PT_TRAVERSE_FAST: 2, abi.PT_TRAVERSE_WIDE: 2}
-            assert got[seed, abi.PT_TRAVERSE_FAST]["tri"] == got[seed, abi.PT_TRAVERSE_WIDE]["tri"] != want[ray]["tri"]
+            assert got[abi.PT_TRAVERSE_WIDE].tobytes() == want[ray].tobytes()
         else:
-            assert ulps == {abi.PT_TRAVERSE_FAST: 0, abi.PT_TRAVERSE_WIDE: 0}
-            assert got[seed, abi.PT_TRAVERSE_FAST].tobytes() == want[ray].tobytes()
-            assert got[seed, abi.PT_TRAVERSE_WIDE]["tri"] != want[ray]["tri"]
+            assert got[abi.PT_TRAVERSE_WIDE]["t"].tobytes() == want[ray]["t"].tobytes()
+            assert got[abi.PT_TRAVERSE_WIDE]["tri"] != want[ray]["tri"]
