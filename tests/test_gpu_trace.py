@@ -296,8 +296,9 @@ def test_the_sweeps_instructive_rays(oracle, gpu_ctx):
     """Two rays the randomised sweep found, kept as they were found.  EXACT returns the recursion's answer
     on both.  Seed 910, ray 18391: a flat axis-aligned triangle whose box is entered (by rounding) exactly at the t of
     a hit in ANOTHER subtree, 2 ulp after the triangle's own t.  A kernel that prunes `best > entry` against the best
-    hit of the whole ray loses it (FAST and WIDE did, until the comparison became non-strict for hits found before the
-    entry was pushed - trace.hip: ptc_worth_entering); the recursion, which only ever compares siblings, does not.
+    hit of the whole ray loses it (FAST and WIDE did, until the comparison became non-strict - in FAST with 2 ulp of
+    slack - for hits found before the entry was pushed: trace.hip, ptc_worth_entering); the recursion, which only ever
+    compares siblings, does not.
     Seed 1912, ray 14942: two coplanar triangles hit at the same t under different children of one binary node: WIDE,
     entering the four grandchildren by their own entry distances, keeps the other one of the tie; FAST keeps the
     recursion's."""
