@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spectral-spp", type=int, default=64, help="samples per pixel PER RANK of the spectral leg (config 3: 64; 0 = skip)")
-    ap.add_argument("--traversal", choices=["wide", "fast", "exact"], default="wide")
+    ap.add_argument("--traversal", choices=["exact", "min_t", "replay"], default="exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --one-device rehearses the N>1 code path on a 1-GPU box")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
@@ -81,7 +81,7 @@ def main():
     build_s = time.time() - t0
     ctx = core.Context(local_rank)
     scene = ctx.scene(arr)
-    ctx.set_traversal({"wide": abi.PT_TRAVERSE_WIDE, "fast": abi.PT_TRAVERSE_FAST, "exact": abi.PT_TRAVERSE_EXACT}[a.traversal])
+    ctx.set_traversal({"exact": abi.PT_TRAVERSE_EXACT, "min_t": abi.PT_TRAVERSE_MIN_T, "replay": abi.PT_TRAVERSE_REPLAY}[a.traversal])
     info = scene.info()
     rays = core.gen_primary_rays(a.width, a.height)
     if world > 1 and rank > 0:
@@ -246,7 +246,7 @@ def main():
                   "random_line_ceiling_per_ns": gj.get("random_lines_per_ns"),
                   "note": "ceilings measured on this GPU model by harness/ptgather (" + gj.get("source", "profiles/") + ")"}
         roofline = {
-            "bound": "hbm", "kernel": "k_trace_exact_persistent" if a.traversal == "exact" else f"k_trace_fast_persistent ({a.traversal})",
+            "bound": "hbm", "kernel": {"exact": "k_trace_scoped_persistent", "min_t": "k_trace_mint_persistent", "replay": "k_trace_replay_persistent"}[a.traversal],
             "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
             "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_ray": b_ray, "n_node": n_node, "n_tri": n_tri, "visit_counts": counts_src,

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -215,20 +215,21 @@ void pt_host_free(void* p);
 int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
                          const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out);
 
-/* Traversal flavour used by both calls above and by pt_render.  All three walk the caller's BVH (same
- * boxes, same triangles, same arithmetic per box and per triangle).  EXACT returns what
- * traverse_recursive returns, on every ray, by construction.  FAST and WIDE return the minimum-t hit,
- * pruning against the best hit of the whole ray (strictly only against hits found in the near sibling's
- * subtree, which is where the recursion compares).  In the randomised sweep (10 000 scenes built to provoke
- * ties and rounding gaps, 2.26 G rays) FAST agreed with the recursion on every ray; WIDE named another
- * triangle in 7 ray tests of 750 M: the other one of an exact equal-t tie in 6, a hit 1-2 ulp farther in 1.
- * On the benchmark scenes no mode differs on any ray. */
-#define PT_TRAVERSE_FAST  0u  /* binary nodes, global-best pruning                                 */
-#define PT_TRAVERSE_EXACT 1u  /* replays traverse_recursive's local pruning and tie rules
-                                 (bvh.rs:265-306) frame by frame; about 0.43 of WIDE's rate        */
-#define PT_TRAVERSE_WIDE  2u  /* two levels of the same tree per step (4 boxes at once, nearest first,
-                                 global-best pruning)                                              */
-#define PT_TRAVERSE_DEFAULT PT_TRAVERSE_WIDE
+/* Traversal flavour used by both calls above and by pt_render.  All walk the caller's BVH (same boxes, same triangles,
+ * same arithmetic per box and per triangle).
+ *   EXACT  (default) returns what traverse_recursive returns (bvh.rs:250-338) on every ray, by construction: the same
+ *          leaves are visited in the same order under the same local rule (the far child is entered iff the near child's
+ *          own result is farther than the far box, bvh.rs:285; the later visit wins an equal-t tie, bvh.rs:299-303), two
+ *          tree levels per memory fetch.  Rays with a non-finite component, and rays that meet a triangle at a non-finite
+ *          distance, are traced by REPLAY inside the same call.
+ *   REPLAY the recursion frame by frame over the binary nodes; same results as EXACT, about half its rate.
+ *   MIN_T  prunes against the best hit of the whole ray instead: returns a hit of minimum t, fastest; WHICH triangle of an
+ *          exact equal-t tie - or of two hits an ulp or two apart where a box's entry distance rounds above the t of its own
+ *          triangle - is not the recursion's choice in general (DESIGN.md 2 counts the cases a randomised sweep found). */
+#define PT_TRAVERSE_MIN_T  0u
+#define PT_TRAVERSE_EXACT  1u
+#define PT_TRAVERSE_REPLAY 2u
+#define PT_TRAVERSE_DEFAULT PT_TRAVERSE_EXACT
 int pt_set_traversal(pt_ctx* ctx, uint32_t mode);
 
 /* ---- seam 3: render (replaces the rayon closure main.rs:58-116) ---------------------------

@@ -180,16 +180,26 @@ Triangle triangle_new(const pt_triangle& t) {
 }
 
 // triangle.rs:82-115
+// Set when a triangle test took the SIGN of a NaN (triangle.rs:91,97,102: f32::is_sign_positive reads the sign bit).  The
+// sign of a NaN that an operation generates or passes on is not specified by IEEE 754 and not portable in Rust either
+// (std docs of is_sign_positive); x86 SSE and gfx950 differ, so on such rays the reference's own answer depends on the CPU
+// it runs on.  pto_trace_nan_flags reports them so that parity tests can leave them out, and say how many there were.
+thread_local bool tl_nan_sign_test = false;
+inline bool sign_differs(float a, float b) {
+    if (a != a || b != b) tl_nan_sign_test = true;
+    return pt_sign_positive(a) != pt_sign_positive(b);
+}
+
 bool triangle_intersect(const Triangle& tr, const Ray& ray, float max_distance, Intersection* out) {
     float det = dot(ray.direction, tr.n);
     if (det == 0.0f) return false;
     float t = tr.d - dot(ray.origin, tr.n);
-    if (pt_sign_positive(max_distance * det - t) != pt_sign_positive(t)) return false;
+    if (sign_differs(max_distance * det - t, t)) return false;
     V3 p = ray.origin * det + ray.direction * t;
     float u = dot(p, tr.n1) + det * tr.d1;
-    if (pt_sign_positive(det - u) != pt_sign_positive(u)) return false;
+    if (sign_differs(det - u, u)) return false;
     float v = dot(p, tr.n2) + det * tr.d2;
-    if (pt_sign_positive(det - u - v) != pt_sign_positive(v)) return false;
+    if (sign_differs(det - u - v, v)) return false;
     float inv_det = 1.0f / det;
     float distance = t * inv_det;
     // approx 0.5.1 relative_eq!(distance, 0.0) with default epsilon = max_relative = f32::EPSILON:
@@ -854,6 +864,26 @@ void pto_trace(const pto_scene* sc, const pt_ray* rays, const uint32_t* start, u
         }
     });
     if (counters) for (auto& c : cnt) { counters[0] += c.nodes; counters[1] += c.tris; }
+}
+
+// pto_trace, and per ray whether any triangle test on its way took the sign of a NaN (see tl_nan_sign_test): on those rays
+// the reference's answer is platform-dependent.
+void pto_trace_nan_flags(const pto_scene* sc, const pt_ray* rays, const uint32_t* start, uint64_t n,
+                         pt_hit* out, uint8_t* nan_flags, int nthreads) {
+    const Scene& s = sc->s;
+    parallel_for(n, nthreads, [&](int, uint64_t b, uint64_t e) {
+        Counters cnt;
+        for (uint64_t i = b; i < e; ++i) {
+            Ray ray(v3(rays[i].o), v3(rays[i].d));
+            TravResult r{false, PT_NO_TRIANGLE, {}};
+            tl_nan_sign_test = false;
+            if (!s.nodes.empty())
+                r = traverse_rec(s.nodes, 0, ray, start ? start[i] : PT_NO_TRIANGLE, s.triangles, INF, cnt);
+            nan_flags[i] = tl_nan_sign_test ? 1 : 0;
+            if (r.some) out[i] = pt_hit{r.tri, r.isect.distance, r.isect.u, r.isect.v};
+            else out[i] = pt_hit{PT_NO_TRIANGLE, 0.0f, 0.0f, 0.0f};
+        }
+    });
 }
 
 // Second oracle: no BVH, every triangle tested in index order, minimum distance wins

@@ -23,10 +23,10 @@ PT_EMIT_NULL = 0
 PT_EMIT_ABSORBED_D65 = 1
 PT_SKY_D65 = 0
 PT_SKY_HOSEK_WILKIE = 1
-PT_TRAVERSE_FAST = 0
+PT_TRAVERSE_MIN_T = 0
 PT_TRAVERSE_EXACT = 1
-PT_TRAVERSE_WIDE = 2
-PT_TRAVERSE_DEFAULT = PT_TRAVERSE_WIDE
+PT_TRAVERSE_REPLAY = 2
+PT_TRAVERSE_DEFAULT = PT_TRAVERSE_EXACT
 PT_RENDER_FINAL = 0
 PT_RENDER_SUM = 1
 PT_TONEMAP_SKIP_NONFINITE = 1

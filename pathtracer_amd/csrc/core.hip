@@ -97,13 +97,12 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     for (auto& ev : ctx->count_ev)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bad("hipEventCreate");
     if ((e = hipHostMalloc((void**)&ctx->h_counters, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bad("hipHostMalloc");
-    if ((e = hipMalloc((void**)&ctx->ticket, 4096)) != hipSuccess) return bad("hipMalloc");
-    if ((e = hipMemset(ctx->ticket, 0, 4096)) != hipSuccess) return bad("hipMemset");
+    if ((e = hipMalloc((void**)&ctx->ticket, PTC_TICKET_BYTES)) != hipSuccess) return bad("hipMalloc");
+    if ((e = hipMemset(ctx->ticket, 0, PTC_TICKET_BYTES)) != hipSuccess) return bad("hipMemset");
     auto env_u32 = [](const char* name, uint32_t def) {
         const char* v = getenv(name);
         return v ? (uint32_t)strtoul(v, nullptr, 10) : def;
     };
-    ctx->tune_variant = env_u32("PTC_TRACE_VARIANT", ctx->tune_variant);
     ctx->tune_blocks_per_cu = std::max(1u, std::min(8u, env_u32("PTC_BLOCKS_PER_CU", ctx->tune_blocks_per_cu)));
     ctx->tune_refill = env_u32("PTC_REFILL", ctx->tune_refill);
     ctx->tune_ticket = env_u32("PTC_TICKET", ctx->tune_ticket);
@@ -124,6 +123,7 @@ extern "C" void pt_shutdown(pt_ctx* ctx) {
     if (ctx->spill) (void)hipFree(ctx->spill);
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->io) (void)hipFree(ctx->io);
+    if (ctx->redo) (void)hipFree(ctx->redo);
     if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->ticket) (void)hipFree(ctx->ticket);
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
@@ -138,7 +138,7 @@ extern "C" void pt_shutdown(pt_ctx* ctx) {
 
 extern "C" int pt_set_traversal(pt_ctx* ctx, uint32_t mode) {
     if (!ctx) return PT_ERR_INVALID;
-    if (mode != PT_TRAVERSE_FAST && mode != PT_TRAVERSE_EXACT && mode != PT_TRAVERSE_WIDE) return ptc_fail(ctx, PT_ERR_INVALID, "unknown traversal mode");
+    if (mode != PT_TRAVERSE_MIN_T && mode != PT_TRAVERSE_EXACT && mode != PT_TRAVERSE_REPLAY) return ptc_fail(ctx, PT_ERR_INVALID, "unknown traversal mode");
     ctx->traversal = mode;
     return PT_OK;
 }
@@ -287,9 +287,9 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
     uint32_t wide_depth = 0;
     const uint32_t wide_mode = lbvh ? 0u : ctx->tune_wide_collapse;
     if (n_internal && wide_mode != 0u) {
-        // wide nodes = internal nodes at odd depth, numbered in node (pre)order; children = the grandchildren (a leaf
-        // child stays), stored in REVERSE binary order: the kernel's stable sort then enters boxes of equal entry
-        // distance right before left, like the recursion (bvh.rs:266-270).  Same rule as k_wide in lbvh.hip.
+        // wide nodes = internal nodes at odd depth, numbered in node (pre)order; slots = the grandchildren at fixed
+        // places in REVERSE binary order (RR, RL | LR, LL; a leaf child takes the first slot of its pair, the other stays
+        // a NaN box): device_types.h.  Same rule as k_wide in lbvh.hip.
         const float nan = std::numeric_limits<float>::quiet_NaN();
         std::vector<uint32_t> wide_index(n_internal);
         uint32_t n_wide = 0;
@@ -301,19 +301,18 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
             float lo[3][4], hi[3][4];
             uint32_t refs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             for (int a = 0; a < 3; ++a) for (int k = 0; k < 4; ++k) { lo[a][k] = nan; hi[a][k] = nan; }
-            int nch = 0;
-            auto take = [&](const float4* q, int side) {
+            auto take = [&](const float4* q, int side, int slot) {
                 const float4 l = q[side ? 2 : 0], h = q[side ? 3 : 1];
-                lo[0][nch] = l.x; lo[1][nch] = l.y; lo[2][nch] = l.z; hi[0][nch] = h.x; hi[1][nch] = h.y; hi[2][nch] = h.z;
+                lo[0][slot] = l.x; lo[1][slot] = l.y; lo[2][slot] = l.z; hi[0][slot] = h.x; hi[1][slot] = h.y; hi[2][slot] = h.z;
                 uint32_t ref; std::memcpy(&ref, side ? &q[1].w : &q[0].w, 4);
-                refs[nch] = (ref & PTC_LEAF_BIT) ? ref : wide_index[ref];
-                ++nch;
+                refs[slot] = (ref & PTC_LEAF_BIT) ? ref : wide_index[ref];
             };
             const float4* q = &nodes[(size_t)r * 4u];
-            for (int side = 1; side >= 0; --side) {
+            for (int side = 1; side >= 0; --side) {          // slots 0, 1: the right child's pair; 2, 3: the left child's
+                const int base = side ? 0 : 2;
                 uint32_t ref; std::memcpy(&ref, side ? &q[1].w : &q[0].w, 4);
-                if (ref & PTC_LEAF_BIT) take(q, side);
-                else { const float4* q2 = &nodes[(size_t)ref * 4u]; take(q2, 1); take(q2, 0); }
+                if (ref & PTC_LEAF_BIT) take(q, side, base);
+                else { const float4* q2 = &nodes[(size_t)ref * 4u]; take(q2, 1, base); take(q2, 0, base + 1); }
             }
             float4* w = &wide[(size_t)wide_index[r] * 8u];
             for (int a = 0; a < 3; ++a) {

@@ -23,13 +23,14 @@
 //   q1 = { l.max.x, l.max.y, l.max.z, bits(right ref) }
 //   q2 = { r.min.x, r.min.y, r.min.z, 0 }
 //   q3 = { r.max.x, r.max.y, r.max.z, 0 }
-// ---- wide node (PT_TRAVERSE_WIDE): 128 B = 8 x float4, two levels of the SAME binary tree collapsed:
-// the children of a wide node are the grandchildren of a binary node (a child that is a leaf stays
-// as it is), stored in REVERSE binary order RR, RL, LR, LL (equal entry distances then resolve right before
-// left, as the recursion does), so every box and every triangle reference is the
-// reference builder's; only the order in which boxes are visited can differ from bvh.rs:265-306.
-//   w0..w2 = min.x, min.y, min.z of children 0..3   w3..w5 = max.x, max.y, max.z of children 0..3
-//   w6 = bits(ref 0..3): leaf bit | triangle, or wide-node index; an empty slot holds a NaN box (never hit)
+// ---- wide node (PT_TRAVERSE_EXACT, PT_TRAVERSE_MIN_T): 128 B = 8 x float4, two levels of the SAME binary tree in one
+// record: the slots of a wide node are the grandchildren of a binary node X, in REVERSE binary order and at FIXED places:
+// slots 0, 1 = the right child's right and left child (RR, RL), slots 2, 3 = the left child's (LR, LL).  A child of X that
+// is a leaf sits in the first slot of its pair (0 or 2) with its own box; the other slot of the pair is empty: NaN box
+// (never hit, and dropped by minNum / maxNum when the child's box is re-derived from its pair: trace_step.h), ref
+// 0xFFFFFFFF.  Every box and every triangle reference is the reference builder's.
+//   w0..w2 = min.x, min.y, min.z of slots 0..3   w3..w5 = max.x, max.y, max.z of slots 0..3
+//   w6 = bits(ref 0..3): leaf bit | triangle, or wide-node index
 //   w7 = unused (keeps the stride one cache line)
 // ---- triangle intersect record: 48 B = 3 x float4 (triangle.rs:17-24)
 //   t0 = { n.xyz, d }   t1 = { n1.xyz, d1 }   t2 = { n2.xyz, d2 }
@@ -91,7 +92,8 @@ struct pt_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t count_ev[8] = {};         // pt_render: one per in-flight live-count readback
     std::vector<hipEvent_t> trace_ev;    // pt_render: pairs around every traversal launch (grown on demand)
-    uint32_t launch_parity = 0;          // which of the two ticket words the next persistent launch uses
+    uint32_t launch_parity = 0;          // which of the two sets of ticket words the next persistent launch uses
+    uint32_t redo_parity = 0;            // which of the two redo counters the next PT_TRAVERSE_EXACT call uses
     uint32_t traversal = PT_TRAVERSE_DEFAULT;
     std::string error;
     pt_stats stats{};
@@ -100,10 +102,11 @@ struct pt_ctx {
     void* spill = nullptr;      size_t spill_bytes = 0;
     void* work = nullptr;       size_t work_bytes = 0;
     void* io = nullptr;         size_t io_bytes = 0;
+    void* redo = nullptr;       size_t redo_bytes = 0;     // PT_TRAVERSE_EXACT: indices of the rays left to the replay kernel
     uint32_t* h_counters = nullptr;      // pinned
-    uint32_t* ticket = nullptr;          // device word: ray-block ticket counter of the persistent kernel
+    uint32_t* ticket = nullptr;          // PTC_TICKET_BYTES on the device: two sets of ticket words (2 KiB each) of the
+                                         // persistent kernels, then the two redo counters (256 B apart)
     // tuning knobs (defaults chosen by measurement; PTC_* environment variables override)
-    uint32_t tune_variant = 1;           // 0: one batch of rays per wave pass, 1: persistent refill
     uint32_t tune_blocks_per_cu = 6;
     uint32_t tune_refill = 16;
     uint32_t tune_wide_collapse = 0;     // wide records of caller-supplied trees: 0 on the device, 1 on the host, 2 both + compare
@@ -126,7 +129,30 @@ int ptc_timed_event(pt_ctx* ctx, size_t i);
         if (_rc != PT_OK) return _rc;                                 \
     } while (0)
 
+#define PTC_TICKET_BYTES 8192u
+
+// Where one traversal launch keeps its device-side scratch when that is not the context's own (grown-on-demand) buffers:
+// the allocation-free entry point (trace_noalloc.hip) points these at its file-scope device array.
+struct ptc_trace_scratch {
+    void* spill;        size_t spill_bytes;      // HBM columns of the per-lane stacks
+    uint32_t* tickets;                            // PTC_TICKET_BYTES, zero before the first launch
+    uint32_t* redo;     size_t redo_bytes;       // PT_TRAVERSE_EXACT: 4 bytes per ray of the batch
+    uint32_t max_blocks;                          // grid cap (0: none): bounds the spill columns
+    uint32_t* launch_parity;                      // host-side words that belong to `tickets`
+    uint32_t* redo_parity;
+};
+
+// Entries per thread of the HBM stack columns.  REPLAY: one frame per binary level.  MIN_T: three pending siblings per
+// wide level.  EXACT: at most a RESTORE and three pending entries per wide level (a re-pushed companion replaces two
+// entries by at most two), and its redo pass replays.
+inline size_t ptc_spill_depth(const DevSceneView& v, uint32_t mode) {
+    const size_t d_replay = (size_t)v.max_depth + 2u, d_mint = 3u * (size_t)v.wide_depth + 2u, d_scoped = 4u * (size_t)v.wide_depth + 4u;
+    return mode == PT_TRAVERSE_REPLAY ? d_replay : mode == PT_TRAVERSE_MIN_T ? d_mint : (d_scoped > d_replay ? d_scoped : d_replay);
+}
+
 // launch helpers implemented in trace.hip / render.hip
+int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
+                        const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out, const ptc_trace_scratch* scratch);
 int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
                      const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out);
 

@@ -7,7 +7,7 @@
 //   3. Karras' binary radix tree over the sorted codes (ties broken by position)
 //   4. boxes bottom-up, one launch per tree level: a node is written once both children were written by
 //      an earlier launch (the boxes of BOTH children live in the parent, device_types.h)
-//   5. depth of every internal node, then the 4-wide records of PT_TRAVERSE_WIDE: internal nodes at odd
+//   5. depth of every internal node, then the 4-wide records (device_types.h): internal nodes at odd
 //      depth (root = 1) become wide nodes, numbered by a prefix sum in node order (root stays 0)
 //
 // Leaf boxes are the exact min/max of the triangle's vertices, as Triangle::aabb (triangle.rs:118-122);
@@ -194,20 +194,21 @@ __global__ __launch_bounds__(LB_BLOCK) void k_wide(const float4* __restrict__ no
     float lo[3][4], hi[3][4];
     uint32_t refs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     for (int a = 0; a < 3; ++a) for (int k = 0; k < 4; ++k) { lo[a][k] = nan; hi[a][k] = nan; }
-    int nch = 0;
-    auto take = [&](const float4* q, int side) {
+    auto take = [&](const float4* q, int side, int slot) {
         const float4 l = q[side ? 2 : 0], h = q[side ? 3 : 1];
-        lo[0][nch] = l.x; lo[1][nch] = l.y; lo[2][nch] = l.z; hi[0][nch] = h.x; hi[1][nch] = h.y; hi[2][nch] = h.z;
+        lo[0][slot] = l.x; lo[1][slot] = l.y; lo[2][slot] = l.z; hi[0][slot] = h.x; hi[1][slot] = h.y; hi[2][slot] = h.z;
         const uint32_t r = __float_as_uint(side ? q[1].w : q[0].w);
-        refs[nch] = (r & PTC_LEAF_BIT) ? r : wide_index[r];
-        ++nch;
+        refs[slot] = (r & PTC_LEAF_BIT) ? r : wide_index[r];
     };
-    // children in REVERSE binary order (RR, RL, LR, LL), as the host-side collapse stores them (core.hip)
+    // slots at fixed places in REVERSE binary order (RR, RL | LR, LL), a leaf child in the first slot of its pair, as the
+    // host-side collapse stores them (core.hip, device_types.h)
     const float4* q = &nodes[4u * (size_t)i];
+#pragma unroll
     for (int side = 1; side >= 0; --side) {
+        const int base = side ? 0 : 2;
         const uint32_t r = __float_as_uint(side ? q[1].w : q[0].w);
-        if (r & PTC_LEAF_BIT) take(q, side);
-        else { const float4* q2 = &nodes[4u * (size_t)r]; take(q2, 1); take(q2, 0); }
+        if (r & PTC_LEAF_BIT) take(q, side, base);
+        else { const float4* q2 = &nodes[4u * (size_t)r]; take(q2, 1, base); take(q2, 0, base + 1); }
     }
     float4* w = &wide[8u * (size_t)wide_index[i]];
     for (int a = 0; a < 3; ++a) {

@@ -8,36 +8,40 @@
 // One ray per lane, wave64.  The traversal stack is a per-lane SHORT stack in LDS laid out
 // [slot][lane] (8-byte entries, so a wave's push/pop is one conflict-free ds_write_b64 /
 // ds_read_b64); it is a ring: when a lane's ring is full the oldest entry spills to a per-lane
-// column in HBM ([depth][thread], coalesced) and comes back when the ring runs dry.  Binary nodes are
-// fetched as 4 x 16-byte loads, wide nodes as 7, triangles as 3 x 16-byte loads per lane.
+// column in HBM ([depth][thread], coalesced) and comes back when the ring runs dry.  Wide records are
+// fetched as 7 x 16-byte loads, binary nodes as 4, triangles as 3 x 16-byte loads per lane.
 //
-// Three flavours (pt_set_traversal):
-//  WIDE   (default) the FAST rule over two levels of the same tree at a time: the 128-byte records of
-//         device_types.h hold the four grandchildren's boxes (bit for bit the binary nodes' boxes); all four
-//         are tested, sorted by entry distance (ties in binary order), the nearest is entered, the others are
-//         pushed farthest first.  Half as many dependent fetches per ray as FAST.
-//  FAST   near-first DFS with ONE global best distance: a subtree is entered iff best > its entry
-//         distance, a leaf hit replaces the best iff t <= best (so among equal t the later
-//         visited wins, as bvh.rs:299-303).  Visits a subset of what the reference visits and
-//         returns the same minimum-t hit.  The comparison with a box is strict only against a hit
-//         found in the near sibling's subtree (ptc_worth_entering below), which keeps equal-t ties and
-//         hits a rounding error apart with the recursion: FAST agreed with it on every ray of the
-//         randomised sweep, WIDE on all but 7 ray tests of 750 M.
-//  EXACT  replays the recursion frame by frame: the far child of a node is entered iff the NEAR
-//         SUBTREE's own result is farther than the far box (bvh.rs:285), no global pruning,
-//         result = first_distance < second_distance ? first : second (bvh.rs:299-303).  Frames
-//         live on the same LDS ring: an "A" frame {far ref, far tmin} waits for the near result,
-//         a "B" frame {first id | tag, first distance} waits for the far result.
-// FAST, WIDE and EXACT run as persistent kernels that hand the next ray to a lane as soon as it is done
-// (RayTickets); PTC_TRACE_VARIANT=0 selects the older one-batch-per-wave kernels of FAST and EXACT.
+// Three flavours (pt_set_traversal), all persistent kernels that hand the next ray to a lane as soon as it is done
+// (RayTickets):
+//  EXACT  (default) returns what traverse_recursive returns, on every ray, by construction - and walks the 128-byte
+//         records of device_types.h, two levels of the binary tree per fetch.  The recursion's rule is LOCAL: the far
+//         child of a node is entered iff the near child's own result is farther than the far box (bvh.rs:285); there is
+//         no pruning against hits from elsewhere, and the result is the minimum-t hit among the leaves so visited, the
+//         later visit winning a tie (bvh.rs:299-303).  So the answer needs one id (the best hit of the whole ray, replaced
+//         iff t <= best, in the recursion's visiting order) and, for every pending far sibling, the minimum t found since
+//         it was pushed: the "scope minimum".  Scopes nest like the stack, so ONE register holds the innermost scope's
+//         minimum (m_cur): a push starts a new scope (m_cur = inf, after parking a finite m_cur in a RESTORE entry), a
+//         pop closes one (the decision `m_cur > entry`, then the parked value folds back in: min).  The per-record
+//         decisions are ptc_wide_step (trace_step.h), shared with the host-side model that the CPU tests check against
+//         the oracle.  A ray with a non-finite component, or one that meets a triangle at a non-finite distance (where
+//         Some(inf) / Some(NaN) and None part ways in bvh.rs:280-303), is handed to REPLAY through a redo list.
+//  REPLAY replays the recursion frame by frame over the binary nodes: an "A" frame {far ref, far tmin} waits for the near
+//         result, a "B" frame {first id | tag, first distance} waits for the far result.  The reference implementation
+//         of the rule on the device, the redo path of EXACT, and selectable on its own.
+//  MIN_T  the fastest: global-best pruning over the wide records (enter a box iff best >= its entry distance, the four
+//         boxes of a record nearest first).  Returns a minimum-t hit; which triangle of an exact equal-t tie, or of two
+//         hits an ulp apart where a box's entry distance rounds above its own triangle's t, is not the recursion's
+//         choice in general.
 //
 // All float arithmetic is written in the reference's operation order and the file is compiled
 // with -ffp-contract=off: no FMA, IEEE division, minNum/maxNum for f32::min/max.
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_types.h"
-#include "../../include/pt_math.h"
+#include "trace_step.h"
 
 #define PTC_BLOCK 256
 #ifndef PTC_SHARDS
@@ -46,82 +50,6 @@
 #define PTC_FIRST 64u              /* rays of a wave's static first block (one per lane) */
 
 namespace {
-
-struct DRay { float ox, oy, oz, dx, dy, dz, ix, iy, iz; };
-
-__device__ __forceinline__ DRay make_ray(float4 o, float4 d) {
-    DRay r;
-    r.ox = o.x; r.oy = o.y; r.oz = o.z;
-    r.dx = d.x; r.dy = d.y; r.dz = d.z;
-    r.ix = 1.0f / d.x; r.iy = 1.0f / d.y; r.iz = 1.0f / d.z;      // bvh.rs:384
-    return r;
-}
-
-// Ray::intersects_aabb (bvh.rs:390-410); returns hit flag, entry distance in tmin
-__device__ __forceinline__ bool slab(const DRay& r, float bx0, float by0, float bz0, float bx1,
-                                     float by1, float bz1, float& tmin_out) {
-    float t1x = (bx0 - r.ox) * r.ix, t2x = (bx1 - r.ox) * r.ix;
-    float t1y = (by0 - r.oy) * r.iy, t2y = (by1 - r.oy) * r.iy;
-    float t1z = (bz0 - r.oz) * r.iz, t2z = (bz1 - r.oz) * r.iz;
-    float tmin = pt_fmin(t1x, t2x);
-    float tmax = pt_fmax(t1x, t2x);
-    tmin = pt_fmax(tmin, pt_fmin(t1y, t2y));
-    tmax = pt_fmin(tmax, pt_fmax(t1y, t2y));
-    tmin = pt_fmax(tmin, pt_fmin(t1z, t2z));
-    tmax = pt_fmin(tmax, pt_fmax(t1z, t2z));
-    tmin = pt_fmax(tmin, 0.0f);
-    tmin_out = tmin;
-    return tmax >= tmin;
-}
-
-// The same test split for the 4-box records: slab_axis2 does one axis of two boxes (packed f32
-// subtract and multiply: one rounding per half, as in `slab`), slab_close the min/max chain of one box.
-typedef float ptc_f2 __attribute__((ext_vector_type(2)));
-struct PairF { ptc_f2 t1, t2; };
-__device__ __forceinline__ PairF slab_axis2(float lo_a, float lo_b, float hi_a, float hi_b, float o, float inv) {
-    const ptc_f2 lo = {lo_a, lo_b}, hi = {hi_a, hi_b}, oo = {o, o}, ii = {inv, inv};
-    PairF p;
-    p.t1 = (lo - oo) * ii;
-    p.t2 = (hi - oo) * ii;
-    return p;
-}
-__device__ __forceinline__ bool slab_close(float t1x, float t2x, float t1y, float t2y, float t1z, float t2z,
-                                           float& tmin_out) {
-    float tmin = pt_fmin(t1x, t2x);
-    float tmax = pt_fmax(t1x, t2x);
-    tmin = pt_fmax(tmin, pt_fmin(t1y, t2y));
-    tmax = pt_fmin(tmax, pt_fmax(t1y, t2y));
-    tmin = pt_fmax(tmin, pt_fmin(t1z, t2z));
-    tmax = pt_fmin(tmax, pt_fmax(t1z, t2z));
-    tmin = pt_fmax(tmin, 0.0f);
-    tmin_out = tmin;
-    return tmax >= tmin;
-}
-
-// Triangle::intersect with max_distance = INFINITY (bvh.rs:332), branch-free until the verdict
-__device__ __forceinline__ bool tri_test(const DRay& r, float4 t0, float4 t1, float4 t2,
-                                         float& dist, float& uo, float& vo) {
-    float det = (r.dx * t0.x + r.dy * t0.y) + r.dz * t0.z;                   // triangle.rs:84
-    float t = t0.w - ((r.ox * t0.x + r.oy * t0.y) + r.oz * t0.z);            // :89
-    float m = pt_inf() * det - t;                                            // :91
-    float px = r.ox * det + r.dx * t;                                        // :95
-    float py = r.oy * det + r.dy * t;
-    float pz = r.oz * det + r.dz * t;
-    float u = ((px * t1.x + py * t1.y) + pz * t1.z) + det * t1.w;            // :96
-    float v = ((px * t2.x + py * t2.y) + pz * t2.z) + det * t2.w;            // :101
-    float du = det - u;
-    float duv = du - v;                                                      // (det - u) - v, :102
-    uint32_t bad = (pt_f2u(m) ^ pt_f2u(t)) | (pt_f2u(du) ^ pt_f2u(u)) | (pt_f2u(duv) ^ pt_f2u(v));
-    float inv = 1.0f / det;                                                  // :106
-    float d = t * inv;                                                       // :108
-    bool ok = (det != 0.0f) && ((bad >> 31) == 0u);
-    // relative_eq!(distance, 0.0): equal, or |distance| <= f32::EPSILON      :110
-    ok = ok && !(d == 0.0f || pt_fabs(d) <= 1.1920928955078125e-7f);
-    dist = d;
-    uo = u * inv;
-    vo = v * inv;
-    return ok;
-}
 
 // ---- per-lane ring stack: LDS window over an HBM column -----------------------------------------
 // `ring` is the block's __shared__ array, slot-major ([slot][thread]); the column is
@@ -140,6 +68,7 @@ struct LaneStack {
 
     __device__ __forceinline__ void reset() { idx = threadIdx.x; cnt = 0u; base = 0u; }
     __device__ __forceinline__ bool empty() const { return (cnt | base) == 0u; }
+    __device__ __forceinline__ uint32_t size() const { return cnt + base; }
     __device__ __forceinline__ void push(uint2* __restrict__ ring, uint32_t a, uint32_t b) {
         if (__builtin_expect(cnt == (uint32_t)S, 0)) {      // ring full: the next free slot holds the oldest entry
             const uint2 old = ring[idx];
@@ -173,11 +102,6 @@ struct LaneStack {
     }
 };
 
-__device__ __forceinline__ void load_node(const float4* nodes, uint32_t idx, float4& q0, float4& q1,
-                                          float4& q2, float4& q3) {
-    const float4* p = nodes + (size_t)idx * 4u;
-    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-}
 
 // ---- dynamic ray reservation of the persistent kernels (wave-uniform state) ---------------------
 // The batch is cut into PTC_SHARDS contiguous shards, each with its own ticket word; a wave works on the shard
@@ -234,120 +158,25 @@ struct RayTickets {
     }
 };
 
-#define PTC_IDLE 0xFFFFFFFFu   /* "needs a pop": leaf bit set, never a valid triangle index */
-
-// FAST / WIDE pruning rule.  The recursion never compares a box with a hit from ANOTHER subtree: it enters every box
-// the ray meets, and skips the far child only if the near child's own result is not farther than the far box
-// (`first.distance > far_min`, strict, bvh.rs:285).  These kernels prune against the best hit of the whole ray, which
-// in exact arithmetic loses nothing; to stay with the recursion where distances are EQUAL (coplanar triangles, flat
-// boxes entered exactly at the triangle's t) the comparison is strict only when the best hit was found after the
+// ---- MIN_T: global-best pruning over the wide records -------------------------------------------------------------------
+// The recursion never compares a box with a hit from ANOTHER subtree: it enters every box the ray meets, and skips the
+// far child only if the near child's own result is not farther than the far box (`first.distance > far_min`, strict,
+// bvh.rs:285).  This kernel prunes against the best hit of the whole ray, which in exact arithmetic loses nothing.  To stay
+// close to the recursion where distances are EQUAL the comparison is strict only when the best hit was found after the
 // entry was pushed - i.e. inside the near sibling's subtree, the one case in which the recursion compares at all - and
-// non-strict otherwise.  The parity of the number of accepted hits travels with every stack entry for that, in bit 30
-// of the reference (free outside EXACT); `tagbit` is that parity, kept in place.  Distances are non-negative, so
-// their bit patterns order like the floats and "strict" is "one less": enter iff bits(best) - 1 >= bits(entry).
-// Against a hit from another subtree FAST's comparison also gives the box 2 ulp: a box's entry distance,
-// (min - o) * inv, and the distance of the triangle inside it, (d - o.n) / det, are rounded independently, and the
-// entry of a flat box can lie an ulp or two above the t of its own triangle.
-// The slack is FAST's alone: on WIDE it cost 4.5 % of the integrator's traversal rate (measured), and WIDE's remaining
-// differences from the recursion are ties of another kind.
-template <bool WIDE>
-__device__ __forceinline__ bool ptc_may_hold_a_hit(float entry, float best_t) {     // nothing found since: no sibling to compare
-    if constexpr (WIDE) return best_t >= entry;
-    else return (int32_t)__float_as_uint(entry) <= (int32_t)(__float_as_uint(best_t) + 2u);
-}
-template <bool WIDE>
-__device__ __forceinline__ bool ptc_worth_entering(uint2 e, float best_t, uint32_t tagbit) {
-    if constexpr (WIDE) {
-        const uint32_t changed = ((e.x ^ tagbit) >> 30) & 1u;
-        return (int32_t)(__float_as_uint(best_t) - changed) >= (int32_t)e.y;
-    } else {
-        const bool changed = ((e.x ^ tagbit) & PTC_FRAME_BIT) != 0u;
-        const uint32_t limit = __float_as_uint(best_t) + (changed ? 0xFFFFFFFFu : 2u);
-        return (int32_t)limit >= (int32_t)e.y;
-    }
-}
-
-// FAST.  Every loop iteration runs three predicated phases, so a lane can visit a node, test the
-// leaf it descends into and pop its next subtree in ONE trip; the wave's trip count is then about
-// the largest per-lane node count instead of the sum of node, leaf and pop steps.
-template <int S, bool QUEUED>
-__global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast(DevSceneView sc, const float4* __restrict__ rays,
-                                                         const uint32_t* __restrict__ start,
-                                                         const uint32_t* __restrict__ queue,
-                                                         const uint32_t* __restrict__ count_ptr, uint32_t n,
-                                                         uint4* __restrict__ out, uint2* __restrict__ spill,
-                                                         uint32_t total_threads) {
-    __shared__ uint2 ring[S * PTC_BLOCK];
-    const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
-    if (count_ptr) n = *count_ptr;
-    LaneStack<S> st;
-    st.spill = spill + gtid;
-    st.spill_stride = total_threads;
-
-    for (uint32_t k = gtid; k < n; k += total_threads) {
-        const uint32_t i = QUEUED ? queue[k] : k;
-        const float4 ro = rays[2 * (size_t)i];
-        const DRay r = make_ray(ro, rays[2 * (size_t)i + 1]);
-        // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
-        const uint32_t skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[i] : PT_NO_TRIANGLE);
-        float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
-        uint32_t best_id = PT_NO_TRIANGLE, tagbit = 0u;
-        st.reset();
-        uint32_t cur = sc.root_ref;
-        bool alive = sc.n_tris != 0u;
-        while (alive) {
-            // ---- phase 1: internal node (bvh.rs:259-325) ----
-            if (!(cur & PTC_LEAF_BIT)) {
-                float4 q0, q1, q2, q3;
-                load_node(sc.nodes, cur, q0, q1, q2, q3);
-                float lt, rt;
-                bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);    // bvh.rs:260
-                bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);    // bvh.rs:261
-                lh = lh && ptc_may_hold_a_hit<false>(lt, best_t);
-                rh = rh && ptc_may_hold_a_hit<false>(rt, best_t);
-                const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
-                const bool left_first = lt < rt;                              // bvh.rs:266
-                if (lh && rh) st.push(ring, (left_first ? rref : lref) | tagbit, __float_as_uint(left_first ? rt : lt));
-                cur = (lh && (left_first || !rh)) ? lref : (rh ? rref : PTC_IDLE);
-            }
-            // ---- phase 2: leaf (bvh.rs:327-336) ----
-            if ((cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
-                const uint32_t tri = cur & PTC_INDEX_MASK;
-                if (tri != skip) {                                            // bvh.rs:329-330
-                    const float4* tp = sc.tris + (size_t)tri * 3u;
-                    float d, u, v;
-                    if (tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
-                        best_t = d; best_u = u; best_v = v; best_id = tri;
-                        tagbit ^= PTC_FRAME_BIT;
-                    }
-                }
-                cur = PTC_IDLE;
-            }
-            // ---- phase 3: pop until something is still worth entering ----
-            while (cur == PTC_IDLE) {
-                if (st.empty()) { alive = false; break; }
-                const uint2 e = st.pop(ring);
-                if (ptc_worth_entering<false>(e, best_t, tagbit)) cur = e.x & ~PTC_FRAME_BIT;
-            }
-        }
-        out[i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
-                            __float_as_uint(best_u), __float_as_uint(best_v));
-    }
-}
-
-// FAST, persistent form.  Traversal lengths have a heavy tail (soup-1M primaries: mean 51 node
-// visits per ray, but the slowest of 64 neighbouring rays needs 141), so a wave that waits for its
-// slowest lane keeps only ~1/3 of its lanes busy.  Here a lane that finishes its ray takes the next
-// one at once: each wave reserves blocks of `ticket_size` (64) consecutive rays from a global ticket counter (one
-// atomic per block, fetched by lane 0 and broadcast) and hands them to idle lanes by ballot +
-// popcount rank, whenever at least `refill` lanes are idle.  Lanes only idle during the final drain.
+// non-strict otherwise.  "Found since the push" is exact: every entry on the stack when a hit is accepted is a pending
+// sibling of an ancestor of the leaf, so `mark` = the stack height at the last accepted hit, lowered to the height after
+// every pop, says it for each popped entry (height after the pop < mark).  Distances are non-negative, so their bit patterns
+// order like the floats and "strict" is "one less": enter iff bits(best) - changed >= bits(entry).
 //
-// WIDE (PT_TRAVERSE_WIDE): the same loop over the two-level records of device_types.h.  A trip tests
-// four boxes (the binary node's grandchildren, same arithmetic per box), sorts the ones worth entering
-// by entry distance, descends into the nearest and pushes the others farthest first.  A ray needs
-// about half as many dependent node fetches, which is what bounds the binary kernel.
-template <int S, bool QUEUED, bool WIDE>
-__global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
+// Persistent with dynamic refill: traversal lengths have a heavy tail (soup-1M primaries: the slowest of 64 neighbouring
+// rays needs ~2.5x the mean), so a lane that finishes its ray takes the next one at once: each wave reserves blocks of
+// `ticket_size` (64) consecutive rays from a ticket word and hands them to idle lanes by ballot + popcount rank whenever
+// at least `refill` lanes are idle.  Every loop trip runs three predicated phases (record: slab tests + ordered push; leaf:
+// triangle test; pop until something is still worth entering), so a lane can visit a record, test the leaf it descends
+// into and pop its next subtree in ONE trip.
+template <int S, bool QUEUED>
+__global__ __launch_bounds__(PTC_BLOCK) void k_trace_mint_persistent(
     DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
     uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket,
@@ -372,7 +201,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
     tk.init(n);
     bool has_ray = false;
     DRay r = {};
-    uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE, tagbit = 0u;
+    uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE, mark = 0u;
     float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
 
     for (;;) {
@@ -384,11 +213,11 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
             if (tk.take(idle, n_idle, lane, !has_ray, n, ticket, ticket_size, k)) {
                 ray_i = QUEUED ? queue[k] : k;
                 const float4 ro = rays[2 * (size_t)ray_i];
-                r = make_ray(ro, rays[2 * (size_t)ray_i + 1]);
+                r = ptc_make_ray(ro, rays[2 * (size_t)ray_i + 1]);
                 // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
                 skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[ray_i] : PT_NO_TRIANGLE);
                 best_t = pt_inf(); best_u = 0.0f; best_v = 0.0f; best_id = PT_NO_TRIANGLE;
-                tagbit = 0u;
+                mark = 0u;
                 st.reset();
                 cur = sc.root_ref;
                 has_ray = true;
@@ -399,49 +228,34 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
             continue;                      // block ran dry mid-refill: reserve another one
         }
         if (has_ray) {
-            // ---- phase 1: internal node (bvh.rs:259-325) ----
+            // ---- phase 1: wide record (two levels of bvh.rs:259-325) ----
             if (!(cur & PTC_LEAF_BIT)) {
-                if constexpr (WIDE) {
-                    const float4* p = sc.wide + (size_t)cur * 8u;
-                    const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5], rw = p[6];
-                    float k0, k1, k2, k3;
-                    uint32_t r0 = __float_as_uint(rw.x), r1 = __float_as_uint(rw.y), r2 = __float_as_uint(rw.z), r3 = __float_as_uint(rw.w);
-                    // the 24 subtractions and 24 products of the four slab tests, two boxes per packed
-                    // instruction (v_pk_add_f32 / v_pk_mul_f32 round each half like the scalar forms)
-                    const PairF ax = slab_axis2(lox.x, lox.y, hix.x, hix.y, r.ox, r.ix), bx = slab_axis2(lox.z, lox.w, hix.z, hix.w, r.ox, r.ix);
-                    const PairF ay = slab_axis2(loy.x, loy.y, hiy.x, hiy.y, r.oy, r.iy), by = slab_axis2(loy.z, loy.w, hiy.z, hiy.w, r.oy, r.iy);
-                    const PairF az = slab_axis2(loz.x, loz.y, hiz.x, hiz.y, r.oz, r.iz), bz = slab_axis2(loz.z, loz.w, hiz.z, hiz.w, r.oz, r.iz);
-                    const bool h0 = slab_close(ax.t1.x, ax.t2.x, ay.t1.x, ay.t2.x, az.t1.x, az.t2.x, k0) && ptc_may_hold_a_hit<true>(k0, best_t);
-                    const bool h1 = slab_close(ax.t1.y, ax.t2.y, ay.t1.y, ay.t2.y, az.t1.y, az.t2.y, k1) && ptc_may_hold_a_hit<true>(k1, best_t);
-                    const bool h2 = slab_close(bx.t1.x, bx.t2.x, by.t1.x, by.t2.x, bz.t1.x, bz.t2.x, k2) && ptc_may_hold_a_hit<true>(k2, best_t);
-                    const bool h3 = slab_close(bx.t1.y, bx.t2.y, by.t1.y, by.t2.y, bz.t1.y, bz.t2.y, k3) && ptc_may_hold_a_hit<true>(k3, best_t);
-                    k0 = h0 ? k0 : pt_inf(); k1 = h1 ? k1 : pt_inf(); k2 = h2 ? k2 : pt_inf(); k3 = h3 ? k3 : pt_inf();
-                    // Ascending entry distance by odd-even transposition: six exchanges of NEIGHBOURS with a strict
-                    // compare, hence stable.  The record holds the children in REVERSE binary order (RR, RL, LR, LL), so
-                    // boxes with equal entry distance are entered right before left, as bvh.rs:266-270 does at every
-                    // binary node (`l_min < r_min` else right first): coincident geometry resolves as in the recursion.
+                const float4* p = sc.wide + (size_t)cur * 8u;
+                const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5], rw = p[6];
+                float k0, k1, k2, k3;
+                uint32_t r0 = __float_as_uint(rw.x), r1 = __float_as_uint(rw.y), r2 = __float_as_uint(rw.z), r3 = __float_as_uint(rw.w);
+                // the 24 subtractions and 24 products of the four slab tests, two boxes per packed instruction
+                const PtcPair ax = ptc_slab_axis2(lox.x, lox.y, hix.x, hix.y, r.ox, r.ix), bx = ptc_slab_axis2(lox.z, lox.w, hix.z, hix.w, r.ox, r.ix);
+                const PtcPair ay = ptc_slab_axis2(loy.x, loy.y, hiy.x, hiy.y, r.oy, r.iy), by = ptc_slab_axis2(loy.z, loy.w, hiy.z, hiy.w, r.oy, r.iy);
+                const PtcPair az = ptc_slab_axis2(loz.x, loz.y, hiz.x, hiz.y, r.oz, r.iz), bz = ptc_slab_axis2(loz.z, loz.w, hiz.z, hiz.w, r.oz, r.iz);
+                const bool h0 = ptc_slab_close(ax.t1.x, ax.t2.x, ay.t1.x, ay.t2.x, az.t1.x, az.t2.x, k0) && best_t >= k0;
+                const bool h1 = ptc_slab_close(ax.t1.y, ax.t2.y, ay.t1.y, ay.t2.y, az.t1.y, az.t2.y, k1) && best_t >= k1;
+                const bool h2 = ptc_slab_close(bx.t1.x, bx.t2.x, by.t1.x, by.t2.x, bz.t1.x, bz.t2.x, k2) && best_t >= k2;
+                const bool h3 = ptc_slab_close(bx.t1.y, bx.t2.y, by.t1.y, by.t2.y, bz.t1.y, bz.t2.y, k3) && best_t >= k3;
+                k0 = h0 ? k0 : pt_inf(); k1 = h1 ? k1 : pt_inf(); k2 = h2 ? k2 : pt_inf(); k3 = h3 ? k3 : pt_inf();
+                // Ascending entry distance by odd-even transposition: six exchanges of NEIGHBOURS with a strict
+                // compare, hence stable.  The record holds the children in REVERSE binary order (RR, RL, LR, LL), so
+                // boxes with equal entry distance are entered right before left, as bvh.rs:266-270 does at every
+                // binary node (`l_min < r_min` else right first).
 #define PTC_CSWAP(ka, kb, ra, rb) { const bool sw = ka > kb; const float tk = sw ? kb : ka; kb = sw ? ka : kb; ka = tk; \
                                     const uint32_t tr = sw ? rb : ra; rb = sw ? ra : rb; ra = tr; }
-                    PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k1, k2, r1, r2)
-                    PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k1, k2, r1, r2)
+                PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k1, k2, r1, r2)
+                PTC_CSWAP(k0, k1, r0, r1) PTC_CSWAP(k2, k3, r2, r3) PTC_CSWAP(k1, k2, r1, r2)
 #undef PTC_CSWAP
-                    if (k3 < pt_inf()) st.push(ring, r3 | tagbit, __float_as_uint(k3));
-                    if (k2 < pt_inf()) st.push(ring, r2 | tagbit, __float_as_uint(k2));
-                    if (k1 < pt_inf()) st.push(ring, r1 | tagbit, __float_as_uint(k1));
-                    cur = (k0 < pt_inf()) ? r0 : PTC_IDLE;
-                } else {
-                    float4 q0, q1, q2, q3;
-                    load_node(sc.nodes, cur, q0, q1, q2, q3);
-                    float lt, rt;
-                    bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);
-                    bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);
-                    lh = lh && ptc_may_hold_a_hit<false>(lt, best_t);
-                    rh = rh && ptc_may_hold_a_hit<false>(rt, best_t);
-                    const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
-                    const bool left_first = lt < rt;                              // bvh.rs:266
-                    if (lh && rh) st.push(ring, (left_first ? rref : lref) | tagbit, __float_as_uint(left_first ? rt : lt));
-                    cur = (lh && (left_first || !rh)) ? lref : (rh ? rref : PTC_IDLE);
-                }
+                if (k3 < pt_inf()) st.push(ring, r3, __float_as_uint(k3));
+                if (k2 < pt_inf()) st.push(ring, r2, __float_as_uint(k2));
+                if (k1 < pt_inf()) st.push(ring, r1, __float_as_uint(k1));
+                cur = (k0 < pt_inf()) ? r0 : PTC_IDLE;
             }
             // ---- phase 2: leaf (bvh.rs:327-336) ----
             if ((cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
@@ -449,9 +263,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                 if (tri != skip) {
                     const float4* tp = sc.tris + (size_t)tri * 3u;
                     float d, u, v;
-                    if (tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
+                    if (ptc_tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
                         best_t = d; best_u = u; best_v = v; best_id = tri;
-                        tagbit ^= PTC_FRAME_BIT;
+                        mark = st.size();
                     }
                 }
                 cur = PTC_IDLE;
@@ -465,111 +279,140 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_fast_persistent(
                     break;
                 }
                 const uint2 e = st.pop(ring);
-                if (ptc_worth_entering<WIDE>(e, best_t, tagbit)) cur = e.x & ~PTC_FRAME_BIT;
+                const uint32_t height = st.size();
+                const uint32_t changed = height < mark ? 1u : 0u;      // the best hit lies in this entry's near sibling
+                mark = ptc_umin(mark, height);
+                if ((int32_t)(__float_as_uint(best_t) - changed) >= (int32_t)e.y) cur = e.x;
             }
         }
     }
 }
 
-// EXACT: frame-by-frame replay of traverse_recursive.
+// ---- EXACT: the recursion's rule over the wide records (see the head of this file) -----------------------------------------
+// redo_list / redo_count: rays this kernel does not answer (ptc_ray_is_regular false, or a triangle met at a non-finite
+// distance); the launcher runs the REPLAY kernel over that list next.  Two counters alternate between calls like the
+// ticket words: this launch clears the one the next call uses.
 template <int S, bool QUEUED>
-__global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact(DevSceneView sc, const float4* __restrict__ rays,
-                                                          const uint32_t* __restrict__ start,
-                                                          const uint32_t* __restrict__ queue,
-                                                          const uint32_t* __restrict__ count_ptr, uint32_t n,
-                                                          uint4* __restrict__ out, uint2* __restrict__ spill,
-                                                          uint32_t total_threads) {
+__global__ __launch_bounds__(PTC_BLOCK) void k_trace_scoped_persistent(
+    DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
+    const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
+    uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket,
+    uint32_t* __restrict__ ticket_next, uint32_t refill, uint32_t ticket_size, uint32_t* __restrict__ redo_list,
+    uint32_t* __restrict__ redo_count, uint32_t* __restrict__ redo_count_next) {
     __shared__ uint2 ring[S * PTC_BLOCK];
     const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     if (count_ptr) n = *count_ptr;
+    if (gtid < PTC_SHARDS) ticket_next[gtid * 64u] = 0u;      // see k_trace_mint_persistent
+    if (gtid == 0u) *redo_count_next = 0u;
     LaneStack<S> st;
     st.spill = spill + gtid;
     st.spill_stride = total_threads;
+    st.reset();
+    if (sc.n_tris == 0u) {          // empty BVH: every ray misses (bvh.rs:364-368)
+        for (uint32_t k = gtid; k < n; k += total_threads) out[QUEUED ? queue[k] : k] = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
+        return;
+    }
 
-    for (uint32_t k = gtid; k < n; k += total_threads) {
-        const uint32_t i = QUEUED ? queue[k] : k;
-        const float4 ro = rays[2 * (size_t)i];
-        const DRay r = make_ray(ro, rays[2 * (size_t)i + 1]);
-        // QUEUED (the integrator's form): the start triangle rides in the ray's pad0
-        const uint32_t skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[i] : PT_NO_TRIANGLE);
-        // value being returned up the (virtual) call stack: None = {NONE_ID, +inf}
-        uint32_t ret_id = PTC_NONE_ID;
-        float ret_t = pt_inf();
-        st.reset();
-        uint32_t cur = sc.root_ref;
-        bool descending = sc.n_tris != 0u;
-        bool alive = descending;
-        while (alive) {
-            if (descending) {
-                if (cur & PTC_LEAF_BIT) {                                     // bvh.rs:327-336
-                    const uint32_t tri = cur & PTC_INDEX_MASK;
-                    ret_id = PTC_NONE_ID; ret_t = pt_inf();
-                    if (tri != skip) {
-                        const float4* tp = sc.tris + (size_t)tri * 3u;
-                        float d, u, v;
-                        if (tri_test(r, tp[0], tp[1], tp[2], d, u, v)) { ret_id = tri; ret_t = d; }
-                    }
-                    descending = false;
+    RayTickets tk;
+    tk.init(n);
+    bool has_ray = false;
+    DRay r = {};
+    uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE;
+    float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
+    float m_cur = pt_inf();          // minimum t found since the newest stack entry was pushed (inf: none)
+
+    for (;;) {
+        // ---- refill ----
+        const unsigned long long idle = __ballot(!has_ray);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!tk.exhausted && (n_idle >= refill || n_idle == 64u)) {
+            uint32_t k;
+            if (tk.take(idle, n_idle, lane, !has_ray, n, ticket, ticket_size, k)) {
+                ray_i = QUEUED ? queue[k] : k;
+                const float4 ro = rays[2 * (size_t)ray_i];
+                r = ptc_make_ray(ro, rays[2 * (size_t)ray_i + 1]);
+                skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[ray_i] : PT_NO_TRIANGLE);
+                if (ptc_ray_is_regular(r)) {
+                    best_t = pt_inf(); best_u = 0.0f; best_v = 0.0f; best_id = PT_NO_TRIANGLE;
+                    m_cur = pt_inf();
+                    st.reset();
+                    cur = sc.root_ref;
+                    has_ray = true;
                 } else {
-                    float4 q0, q1, q2, q3;
-                    load_node(sc.nodes, cur, q0, q1, q2, q3);
-                    float lt, rt;
-                    const bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);
-                    const bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);
-                    const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
-                    if (lh && rh) {                                           // bvh.rs:264-270
-                        const bool left_first = lt < rt;
-                        // A frame: far ref (tag bit clear) + far entry distance
-                        st.push(ring, left_first ? rref : lref, __float_as_uint(left_first ? rt : lt));
-                        cur = left_first ? lref : rref;
-                    } else if (lh) {
-                        cur = lref;                                           // bvh.rs:308-315
-                    } else if (rh) {
-                        cur = rref;                                           // bvh.rs:316-323
-                    } else {
-                        ret_id = PTC_NONE_ID; ret_t = pt_inf();               // bvh.rs:324
-                        descending = false;
-                    }
-                }
-            } else {
-                if (st.empty()) { alive = false; break; }
-                const uint2 e = st.pop(ring);
-                const bool is_b = ((e.x & PTC_FRAME_BIT) != 0u) && ((e.x & PTC_LEAF_BIT) == 0u);
-                if (!is_b) {
-                    // near subtree returned `ret`; bvh.rs:280-285
-                    const float first_distance = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
-                    if (first_distance > __uint_as_float(e.y)) {
-                        st.push(ring, PTC_FRAME_BIT | ret_id, __float_as_uint(ret_t));   // B frame keeps `first`
-                        cur = e.x;
-                        descending = true;
-                    }
-                    // else: return first_intersection unchanged (bvh.rs:304-306)
-                } else {
-                    // far subtree returned `ret`; bvh.rs:294-303
-                    const uint32_t f_id = e.x & PTC_INDEX_MASK;
-                    const float f_t = __uint_as_float(e.y);
-                    const float fd = (f_id != PTC_NONE_ID) ? f_t : pt_inf();
-                    const float sd = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
-                    if (fd < sd) { ret_id = f_id; ret_t = f_t; }
+                    redo_list[atomicAdd(redo_count, 1u)] = ray_i;
                 }
             }
         }
-        uint4 o = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
-        if (ret_id != PTC_NONE_ID) {
-            // u, v of the winner: the same arithmetic on the same inputs gives the same bits
-            const float4* tp = sc.tris + (size_t)ret_id * 3u;
-            float d, u, v;
-            tri_test(r, tp[0], tp[1], tp[2], d, u, v);
-            o = make_uint4(ret_id, __float_as_uint(d), __float_as_uint(u), __float_as_uint(v));
+        if (__ballot(has_ray) == 0ull) {
+            if (tk.exhausted) break;
+            continue;
         }
-        out[i] = o;
+        if (has_ray) {
+            // ---- phase 1: wide record = bvh.rs:259-325 at a binary node and at the child it enters ----
+            if (!(cur & PTC_LEAF_BIT)) {
+                const float4* p = sc.wide + (size_t)cur * 8u;
+                const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5], rw = p[6];
+                PtcWideStep s;
+                ptc_wide_step(r, lox, loy, loz, hix, hiy, hiz, rw, s);
+                // a push opens a scope: a finite m_cur is parked below it (one RESTORE covers all pushes of this visit)
+                if ((s.v0 || s.v1 || s.v2) && m_cur < pt_inf()) { st.push(ring, PTC_RESTORE, __float_as_uint(m_cur)); m_cur = pt_inf(); }
+                if (s.v0) st.push(ring, s.ref0, __float_as_uint(s.e0));
+                if (s.v1) st.push(ring, s.ref1, __float_as_uint(s.e1));
+                if (s.v2) st.push(ring, s.ref2, __float_as_uint(s.e2));
+                cur = s.cur;
+            }
+            // ---- phase 2: leaf (bvh.rs:327-336) ----
+            if ((cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
+                const uint32_t tri = cur & PTC_INDEX_MASK;
+                if (tri != skip) {
+                    const float4* tp = sc.tris + (size_t)tri * 3u;
+                    float d, u, v;
+                    if (ptc_tri_test(r, tp[0], tp[1], tp[2], d, u, v)) {
+                        if (!(pt_fabs(d) < pt_inf())) {          // Some(inf) / Some(NaN): only the frames get those right
+                            redo_list[atomicAdd(redo_count, 1u)] = ray_i;
+                            has_ray = false;
+                        }
+                        if (d <= best_t) { best_t = d; best_u = u; best_v = v; best_id = tri; }    // later visit wins a tie (bvh.rs:299-303)
+                        m_cur = d < m_cur ? d : m_cur;
+                    }
+                }
+                cur = PTC_IDLE;
+            }
+            // ---- phase 3: pop; an empty stack ends the ray ----
+            while (has_ray && cur == PTC_IDLE) {
+                if (st.empty()) {
+                    out[ray_i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
+                                            __float_as_uint(best_u), __float_as_uint(best_v));
+                    has_ray = false;
+                    break;
+                }
+                const uint2 e = st.pop(ring);
+                if (e.x == PTC_RESTORE) {                          // the enclosing scope's minimum so far
+                    const float parked = __uint_as_float(e.y);
+                    m_cur = parked < m_cur ? parked : m_cur;
+                    continue;
+                }
+                const bool visit = m_cur > __uint_as_float(e.y);   // first_distance > second_child_min (bvh.rs:285)
+                if (e.x & PTC_COMPANION) {                          // the far child's other grandchild lies directly below
+                    const uint2 c = st.pop(ring);
+                    if (visit) {                                    // entering the far child: its far grandchild waits for the near one
+                        if (m_cur < pt_inf()) { st.push(ring, PTC_RESTORE, __float_as_uint(m_cur)); m_cur = pt_inf(); }
+                        st.push(ring, c.x, c.y);
+                    }
+                }
+                if (visit) cur = e.x & ~PTC_COMPANION;
+            }
+        }
     }
 }
 
-// EXACT, persistent form: the same frames, with the ray reservation of the FAST kernel (a lane whose recursion has
-// returned takes the next ray at once) and the three phases per trip (node step, leaf, returns).
-template <int S, bool QUEUED>
-__global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact_persistent(
+// ---- REPLAY: the recursion frame by frame over the binary nodes -------------------------------------------------------------
+// Leaf refs carry PTC_LEAF_BIT with PTC_FRAME_BIT clear (indices < 2^30), internal refs have both clear, so an A frame
+// never looks like a B frame.  QUEUED: ray indices come from `queue`; PADSTART: the start triangle rides in the ray's pad0
+// (the integrator's rays) instead of `start`.
+template <int S, bool QUEUED, bool PADSTART>
+__global__ __launch_bounds__(PTC_BLOCK) void k_trace_replay_persistent(
     DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
     uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket,
@@ -578,7 +421,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact_persistent(
     const uint32_t gtid = blockIdx.x * PTC_BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     if (count_ptr) n = *count_ptr;
-    if (gtid < PTC_SHARDS) ticket_next[gtid * 64u] = 0u;      // see k_trace_fast_persistent
+    if (gtid < PTC_SHARDS) ticket_next[gtid * 64u] = 0u;      // see k_trace_mint_persistent
     LaneStack<S> st;
     st.spill = spill + gtid;
     st.spill_stride = total_threads;
@@ -603,8 +446,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact_persistent(
             if (tk.take(idle, n_idle, lane, !has_ray, n, ticket, ticket_size, k)) {
                 ray_i = QUEUED ? queue[k] : k;
                 const float4 ro = rays[2 * (size_t)ray_i];
-                r = make_ray(ro, rays[2 * (size_t)ray_i + 1]);
-                skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[ray_i] : PT_NO_TRIANGLE);
+                r = ptc_make_ray(ro, rays[2 * (size_t)ray_i + 1]);
+                skip = PADSTART ? __float_as_uint(ro.w) : (start ? start[ray_i] : PT_NO_TRIANGLE);
                 ret_id = PTC_NONE_ID; ret_t = pt_inf();
                 st.reset();
                 cur = sc.root_ref;
@@ -619,11 +462,11 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact_persistent(
         if (has_ray) {
             // ---- phase 1: internal node (bvh.rs:259-325) ----
             if (descending && !(cur & PTC_LEAF_BIT)) {
-                float4 q0, q1, q2, q3;
-                load_node(sc.nodes, cur, q0, q1, q2, q3);
+                const float4* q = sc.nodes + (size_t)cur * 4u;
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                 float lt, rt;
-                const bool lh = slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);
-                const bool rh = slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);
+                const bool lh = ptc_slab(r, q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, lt);    // bvh.rs:260
+                const bool rh = ptc_slab(r, q2.x, q2.y, q2.z, q3.x, q3.y, q3.z, rt);    // bvh.rs:261
                 const uint32_t lref = __float_as_uint(q0.w), rref = __float_as_uint(q1.w);
                 const bool left_first = lt < rt;                              // bvh.rs:266
                 // A frame: far ref (tag bit clear) + far entry distance
@@ -638,7 +481,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact_persistent(
                 if (tri != skip) {
                     const float4* tp = sc.tris + (size_t)tri * 3u;
                     float d, u, v;
-                    if (tri_test(r, tp[0], tp[1], tp[2], d, u, v)) { ret_id = tri; ret_t = d; }
+                    if (ptc_tri_test(r, tp[0], tp[1], tp[2], d, u, v)) { ret_id = tri; ret_t = d; }
                 }
                 descending = false;
             }
@@ -650,7 +493,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact_persistent(
                         // u, v of the winner: the same arithmetic on the same inputs gives the same bits
                         const float4* tp = sc.tris + (size_t)ret_id * 3u;
                         float d, u, v;
-                        tri_test(r, tp[0], tp[1], tp[2], d, u, v);
+                        ptc_tri_test(r, tp[0], tp[1], tp[2], d, u, v);
                         o = make_uint4(ret_id, __float_as_uint(d), __float_as_uint(u), __float_as_uint(v));
                     }
                     out[ray_i] = o;
@@ -683,66 +526,89 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_exact_persistent(
 
 }  // namespace
 
-// Leaf refs carry PTC_LEAF_BIT with PTC_FRAME_BIT clear (indices < 2^30), internal refs have both
-// clear, so an A frame never looks like a B frame.
-
-int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
-                     const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out) {
+// Everything a launch of one traversal flavour needs beyond its arguments: grid, spill columns, ticket words.
+// `scratch` selects where the spill columns, ticket words and redo list live: the context's own buffers (grown on demand),
+// or the caller's (ptc_trace_scratch, trace_noalloc.hip: nothing is allocated then).
+int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
+                        const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out, const ptc_trace_scratch* scratch) {
     if (n == 0) return PT_OK;
     if (n > 0xF0000000u) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "more than 0xF0000000 rays in one batch");
     const DevSceneView& v = scene->view;
     // resident grid: waves_per_simd blocks of 256 per CU at most; fewer when the batch is small
     uint32_t max_blocks = (uint32_t)ctx->n_cus * ctx->tune_blocks_per_cu;
+    if (scratch && scratch->max_blocks && max_blocks > scratch->max_blocks) max_blocks = scratch->max_blocks;
     uint32_t blocks = (n + PTC_BLOCK - 1) / PTC_BLOCK;
     if (blocks > max_blocks) blocks = max_blocks;
-    // the persistent kernel's static first blocks assume every block label (blockIdx % PTC_SHARDS) has the
+    // the persistent kernels' static first blocks assume every block label (blockIdx % PTC_SHARDS) has the
     // same number of blocks; surplus blocks find nothing to do
     blocks = (blocks + PTC_SHARDS - 1u) / PTC_SHARDS * PTC_SHARDS;
     const uint32_t total_threads = blocks * PTC_BLOCK;
-    // HBM spill columns: depth entries per thread (EXACT needs one frame per tree level too)
-    // (WIDE pushes up to three siblings per level)
-    const size_t depth = ctx->traversal == PT_TRAVERSE_WIDE ? 3u * (size_t)v.wide_depth + 2u : (size_t)v.max_depth + 2u;
-    int rc = ptc_reserve(ctx, &ctx->spill, &ctx->spill_bytes, depth * total_threads * sizeof(uint2), "spill");
-    if (rc != PT_OK) return rc;
-    constexpr int S = 8;
+    const uint32_t mode = ctx->traversal;
+    const size_t depth = ptc_spill_depth(v, mode);          // HBM spill columns, entries per thread
+    const size_t spill_need = depth * total_threads * sizeof(uint2);
+    uint2* spill = nullptr;
+    uint32_t *tickets = nullptr, *redo_list = nullptr;
+    if (scratch) {
+        if (spill_need > scratch->spill_bytes) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "scene too deep for the fixed traversal scratch");
+        if (mode == PT_TRAVERSE_EXACT && (size_t)n * sizeof(uint32_t) > scratch->redo_bytes) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "batch too large for the fixed traversal scratch");
+        spill = reinterpret_cast<uint2*>(scratch->spill);
+        tickets = scratch->tickets;
+        redo_list = scratch->redo;
+    } else {
+        int rc = ptc_reserve(ctx, &ctx->spill, &ctx->spill_bytes, spill_need, "spill");
+        if (rc != PT_OK) return rc;
+        if (mode == PT_TRAVERSE_EXACT && (rc = ptc_reserve(ctx, &ctx->redo, &ctx->redo_bytes, (size_t)n * sizeof(uint32_t), "redo list")) != PT_OK) return rc;
+        spill = reinterpret_cast<uint2*>(ctx->spill);
+        tickets = ctx->ticket;
+        redo_list = reinterpret_cast<uint32_t*>(ctx->redo);
+    }
+    uint32_t& parity = scratch ? *scratch->launch_parity : ctx->launch_parity;
+    uint32_t& redo_parity = scratch ? *scratch->redo_parity : ctx->redo_parity;
     const float4* rays = reinterpret_cast<const float4*>(d_rays);
     uint4* out = reinterpret_cast<uint4*>(d_out);
-    uint2* spill = reinterpret_cast<uint2*>(ctx->spill);
     dim3 grid(blocks), block(PTC_BLOCK);
-#define PTC_LAUNCH(kern, ...) hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, v, rays, d_start, d_queue, d_count, n, out, spill, total_threads, ##__VA_ARGS__)
-    if (ctx->traversal == PT_TRAVERSE_EXACT && ctx->tune_variant == 0) {
-        if (d_queue) PTC_LAUNCH((k_trace_exact<S, true>));
-        else PTC_LAUNCH((k_trace_exact<S, false>));
-    } else if (ctx->tune_variant == 0 && ctx->traversal != PT_TRAVERSE_WIDE) {
-        if (d_queue) PTC_LAUNCH((k_trace_fast<S, true>));
-        else PTC_LAUNCH((k_trace_fast<S, false>));
+    const bool q = d_queue != nullptr;
+    const uint32_t refill = ctx->tune_refill < 1u ? 1u : (ctx->tune_refill > 64u ? 64u : ctx->tune_refill);
+    const uint32_t tsize = ctx->tune_ticket < 1u ? 1u : (ctx->tune_ticket > 1024u ? 1024u : ctx->tune_ticket);
+    // this launch's ticket words (sets 2 KiB apart) and the set it clears for the next launch
+    auto next_tickets = [&](uint32_t*& cur_set, uint32_t*& next_set) {
+        cur_set = tickets + 512u * parity;
+        next_set = tickets + 512u * (parity ^ 1u);
+        parity ^= 1u;
+    };
+    uint32_t *tk = nullptr, *tk_next = nullptr;
+    next_tickets(tk, tk_next);
+#define PTC_LAUNCH(kern, qptr, cptr, ...) hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, v, rays, d_start, qptr, cptr, n, out, spill, total_threads, tk, tk_next, refill, tsize, ##__VA_ARGS__)
+    if (mode == PT_TRAVERSE_REPLAY) {
+        if (q) PTC_LAUNCH((k_trace_replay_persistent<12, true, true>), d_queue, d_count);
+        else PTC_LAUNCH((k_trace_replay_persistent<12, false, false>), d_queue, d_count);
+    } else if (mode == PT_TRAVERSE_MIN_T) {
+        if (q) PTC_LAUNCH((k_trace_mint_persistent<12, true>), d_queue, d_count);
+        else PTC_LAUNCH((k_trace_mint_persistent<12, false>), d_queue, d_count);
     } else {
-        uint32_t* const ticket = ctx->ticket + 512u * ctx->launch_parity;         // this launch's counters (256 B apart)
-        uint32_t* const ticket_next = ctx->ticket + 512u * (ctx->launch_parity ^ 1u);
-        ctx->launch_parity ^= 1u;
-        const bool q = d_queue != nullptr;
-#define PTC_PERS(SS, W) do { if (q) PTC_LAUNCH((k_trace_fast_persistent<SS, true, W>), ticket, ticket_next, refill, tsize); else PTC_LAUNCH((k_trace_fast_persistent<SS, false, W>), ticket, ticket_next, refill, tsize); } while (0)
-        const uint32_t refill = ctx->tune_refill < 1u ? 1u : (ctx->tune_refill > 64u ? 64u : ctx->tune_refill);
-        const uint32_t tsize = ctx->tune_ticket < 1u ? 1u : (ctx->tune_ticket > 1024u ? 1024u : ctx->tune_ticket);
-        if (ctx->traversal == PT_TRAVERSE_EXACT) {
-            if (q) PTC_LAUNCH((k_trace_exact_persistent<12, true>), ticket, ticket_next, refill, tsize);
-            else PTC_LAUNCH((k_trace_exact_persistent<12, false>), ticket, ticket_next, refill, tsize);
-        } else if (ctx->traversal == PT_TRAVERSE_WIDE) {
-            switch (ctx->tune_ring) {
-                case 8:  PTC_PERS(8, true); break;
-                case 10: PTC_PERS(10, true); break;
-                case 14: PTC_PERS(14, true); break;
-                case 16: PTC_PERS(16, true); break;
-                default: PTC_PERS(12, true); break;
-            }
-        } else switch (ctx->tune_ring) {
-            case 8:  PTC_PERS(8, false); break;
-            case 10: PTC_PERS(10, false); break;
-            case 16: PTC_PERS(16, false); break;
-            default: PTC_PERS(12, false); break;
+        uint32_t* const redo_count = tickets + 1024u + 64u * redo_parity;
+        uint32_t* const redo_count_next = tickets + 1024u + 64u * (redo_parity ^ 1u);
+        redo_parity ^= 1u;
+#define PTC_SCOPED(SS) do { if (q) PTC_LAUNCH((k_trace_scoped_persistent<SS, true>), d_queue, d_count, redo_list, redo_count, redo_count_next); \
+                            else PTC_LAUNCH((k_trace_scoped_persistent<SS, false>), d_queue, d_count, redo_list, redo_count, redo_count_next); } while (0)
+        switch (ctx->tune_ring) {
+            case 8:  PTC_SCOPED(8); break;
+            case 10: PTC_SCOPED(10); break;
+            case 14: PTC_SCOPED(14); break;
+            case 16: PTC_SCOPED(16); break;
+            default: PTC_SCOPED(12); break;
         }
-#undef PTC_PERS
+#undef PTC_SCOPED
+        // the redo pass: whatever the scoped kernel listed (usually nothing: the launch then finds a zero count and ends)
+        next_tickets(tk, tk_next);
+        if (q) PTC_LAUNCH((k_trace_replay_persistent<12, true, true>), redo_list, redo_count);
+        else PTC_LAUNCH((k_trace_replay_persistent<12, true, false>), redo_list, redo_count);
     }
 #undef PTC_LAUNCH
     return ptc_hip(ctx, hipGetLastError(), "trace kernel launch");
+}
+
+int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
+                     const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out) {
+    return ptc_launch_trace_in(ctx, scene, d_rays, d_start, d_queue, d_count, n, d_out, nullptr);
 }

@@ -211,7 +211,7 @@ static void traverse_and_render_match_the_oracle(Device& dev) {
     const std::vector<Ray> rays = cam.generate_rays();
     std::vector<Hit> want(rays.size());
     pto_trace(o, rays.data(), nullptr, rays.size(), want.data(), nullptr, 8);
-    for (uint32_t mode : {PT_TRAVERSE_WIDE, PT_TRAVERSE_FAST, PT_TRAVERSE_EXACT}) {
+    for (uint32_t mode : {PT_TRAVERSE_MIN_T, PT_TRAVERSE_REPLAY, PT_TRAVERSE_EXACT}) {
         dev.set_traversal(mode);
         const std::vector<Hit> got = scene.traverse(rays);
         CHECK(same_bits(got.data(), want.data(), got.size() * sizeof(Hit)));

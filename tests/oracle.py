@@ -63,6 +63,7 @@ class Oracle:
             "pto_scene_n_nodes": (u32, [vp]),
             "pto_scene_get_nodes": (None, [vp, vp]),
             "pto_trace": (None, [vp, vp, vp, u64, vp, C.POINTER(u64), i32]),
+            "pto_trace_nan_flags": (None, [vp, vp, vp, u64, vp, vp, i32]),
             "pto_trace_brute": (None, [vp, vp, vp, u64, vp, i32]),
             "pto_trace_globalbest_stats": (None, [vp, vp, u64, vp, C.POINTER(u64), vp]),
             "pto_evaluate_sky": (None, [vp, pf, pf, pf]),
@@ -159,6 +160,15 @@ class Oracle:
         cnt = (C.c_uint64 * 2)(0, 0)
         self.L.pto_trace(scene.handle, abi.ptr(rays), abi.ptr(st), rays.size, abi.ptr(out), cnt, self.nthreads)
         return (out, (cnt[0], cnt[1])) if count else out
+
+    def trace_nan_flags(self, scene, rays, start=None):
+        """trace(), and per ray whether a triangle test took the sign of a NaN (the reference's answer is then platform-dependent)."""
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY)
+        out = np.zeros(rays.size, dtype=abi.HIT)
+        flags = np.zeros(rays.size, dtype=np.uint8)
+        st = None if start is None else np.ascontiguousarray(start, dtype=np.uint32)
+        self.L.pto_trace_nan_flags(scene.handle, abi.ptr(rays), abi.ptr(st), rays.size, abi.ptr(out), abi.ptr(flags), self.nthreads)
+        return out, flags.astype(bool)
 
     def trace_brute(self, scene, rays, start=None):
         rays = np.ascontiguousarray(rays, dtype=abi.RAY)

@@ -101,7 +101,7 @@ def test_libm_build_of_the_oracle_bounds_the_pt_math_substitution():
 # ---- GPU: HIP path vs fixtures ----------------------------------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_WIDE])
+@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_MIN_T, abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY])
 def test_gpu_reproduces_hit_fixture(gpu_ctx, soup1m, golden_hits, mode):
     hp, hb, bstart = golden_hits
     sc = gpu_ctx.scene(soup1m)
@@ -114,7 +114,7 @@ def test_gpu_reproduces_hit_fixture(gpu_ctx, soup1m, golden_hits, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_WIDE])
+@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_MIN_T])
 def test_gpu_full_size_batch_checksum(gpu_ctx, soup1m, mode):
     """BASELINE configs[1] at full size: all 2 073 600 primary hits, CRC32 against the oracle's."""
     g = json.load(open(os.path.join(G, "soup1m_primary_counts.json")))

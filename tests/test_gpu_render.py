@@ -47,7 +47,7 @@ def test_box_scene(oracle, gpu_ctx):
     assert st.paths == 96 * 64 * 4 and st.segments >= st.paths
 
 
-@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_WIDE])
+@pytest.mark.parametrize("mode", [abi.PT_TRAVERSE_MIN_T, abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY])
 def test_soup_with_hosek_wilkie_sky(oracle, gpu_ctx, mode):
     arr = workloads.soup_scene(20_000, sky=workloads.hw_sky())
     gpu_ctx.set_traversal(mode)

@@ -11,7 +11,7 @@ from tests.golden import fixture_inputs as fi
 
 pytestmark = pytest.mark.gpu
 
-MODES = [abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_WIDE]
+MODES = [abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY, abi.PT_TRAVERSE_MIN_T]
 
 
 def bounce_rays(rng, hits, rays, n):
@@ -268,8 +268,8 @@ def test_scene_bvh_round_trip_of_caller_nodes(gpu_ctx, n_tris):
 @pytest.mark.parametrize("n_tris", [1, 2, 3, 64, 20_000, 300_000])
 def test_device_built_tree_is_a_reference_tree(oracle, gpu_ctx, n_tris):
     """The device-built tree, read back as `BVH.nodes`, is a tree the reference's own recursion can walk: the CPU
-    restatement of traverse_recursive over it returns what the GPU returns, bit for bit - ids at ties included in EXACT
-    mode, and in FAST / WIDE as well on these scenes - and creating a scene from the read-back nodes gives the same tree
+    restatement of traverse_recursive over it returns what the GPU returns, bit for bit - ids at ties included in EXACT and
+    REPLAY mode, and in MIN_T as well on these scenes - and creating a scene from the read-back nodes gives the same tree
     again."""
     arr = workloads.soup_scene(n_tris)
     gsc = gpu_ctx.scene(arr, lbvh=True)
@@ -283,7 +283,7 @@ def test_device_built_tree_is_a_reference_tree(oracle, gpu_ctx, n_tris):
     start = np.where(np.arange(rays.size) % 3 == 0, want["tri"], abi.PT_NO_TRIANGLE).astype(np.uint32)
     want_s = oracle.trace(osc, rays, start)
     try:
-        for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_WIDE):
+        for mode in MODES:
             gpu_ctx.set_traversal(mode)
             assert gpu_ctx.trace(gsc, rays).tobytes() == want.tobytes(), mode
             assert gpu_ctx.trace(gsc, rays, start).tobytes() == want_s.tobytes(), mode
@@ -293,37 +293,63 @@ def test_device_built_tree_is_a_reference_tree(oracle, gpu_ctx, n_tris):
 
 
 def test_the_sweeps_instructive_rays(oracle, gpu_ctx):
-    """Two rays the randomised sweep found, kept as they were found.  EXACT returns the recursion's answer
-    on both.  Seed 910, ray 18391: a flat axis-aligned triangle whose box is entered (by rounding) exactly at the t of
-    a hit in ANOTHER subtree, 2 ulp after the triangle's own t.  A kernel that prunes `best > entry` against the best
-    hit of the whole ray loses it (FAST and WIDE did, until the comparison became non-strict - in FAST with 2 ulp of
-    slack - for hits found before the entry was pushed: trace.hip, ptc_worth_entering); the recursion, which only ever
-    compares siblings, does not.
-    Seed 1912, ray 14942: two coplanar triangles hit at the same t under different children of one binary node: WIDE,
-    entering the four grandchildren by their own entry distances, keeps the other one of the tie; FAST keeps the
-    recursion's."""
+    """Rays the randomised sweep of round 1 found, kept as they were found.  EXACT (the default) and REPLAY
+    return the recursion's answer on all of them, as on every other ray; MIN_T returns a hit of the same distance to
+    within rounding.
+    Seed 910, ray 18391: a flat axis-aligned triangle whose box is entered (by rounding) exactly at the t of a hit in ANOTHER
+    subtree, 2 ulp after the triangle's own t: a kernel that prunes `best > entry` against the best hit of the whole ray
+    loses it; the recursion, which only ever compares siblings, does not.
+    Seed 1912, ray 14942: two coplanar triangles hit at the same t under different children of one binary node: entering the
+    four grandchildren by their own entry distances keeps the other one of the tie.
+    Seed 8824, rays 2669 and 11174: equal t behind an equal entry distance, and the same with a rounding gap on top."""
     from tests import fuzz_scenes
-    for seed, ray in ((910, 18391), (1912, 14942)):
+    for seed, special in ((910, [18391]), (1912, [14942]), (8824, [2669, 11174])):
         rng = np.random.default_rng(seed)
         tris, mats, sky, scale, images = fuzz_scenes.random_scene(rng)
         arr = abi.SceneArrays(tris, core.bvh_build(tris), mats, sky, images)
         rays = fuzz_scenes.random_rays(rng, 20000, scale)
         want = oracle.trace(oracle.scene(arr), rays)
         gsc = gpu_ctx.scene(arr)
-        got = {}
         try:
-            for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_WIDE):
+            for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY):
                 gpu_ctx.set_traversal(mode)
-                hits = gpu_ctx.trace(gsc, rays)
-                others = np.arange(rays.size) != ray
-                assert hits[others].tobytes() == want[others].tobytes(), (seed, mode)
-                got[mode] = hits[ray]
+                assert gpu_ctx.trace(gsc, rays).tobytes() == want.tobytes(), (seed, mode)
+            gpu_ctx.set_traversal(abi.PT_TRAVERSE_MIN_T)
+            hits = gpu_ctx.trace(gsc, rays)
+            others = ~np.isin(np.arange(rays.size), special)
+            assert hits[others].tobytes() == want[others].tobytes(), seed
+            for ray in special:
+                assert (hits[ray]["tri"] == abi.PT_NO_TRIANGLE) == (want[ray]["tri"] == abi.PT_NO_TRIANGLE)
+                assert abs(int(hits[ray:ray + 1]["t"].view(np.int32)[0]) - int(want[ray:ray + 1]["t"].view(np.int32)[0])) <= 4
         finally:
             gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
-        assert got[abi.PT_TRAVERSE_EXACT].tobytes() == want[ray].tobytes()
-        assert got[abi.PT_TRAVERSE_FAST].tobytes() == want[ray].tobytes()
-        if seed == 910:
-            assert got[abi.PT_TRAVERSE_WIDE].tobytes() == want[ray].tobytes()
-        else:
-            assert got[abi.PT_TRAVERSE_WIDE]["t"].tobytes() == want[ray]["t"].tobytes()
-            assert got[abi.PT_TRAVERSE_WIDE]["tri"] != want[ray]["tri"]
+
+
+def test_irregular_rays_and_non_finite_hits_take_the_replay_path(oracle, gpu_ctx):
+    """What EXACT hands to REPLAY inside the same call: rays with an infinite or NaN component, and rays that meet a
+    triangle at a non-finite distance (a denormal determinant: 1 / det overflows, t * inf is inf or NaN) - where Some(inf),
+    Some(NaN) and None part ways in bvh.rs:280-303.  Every mode that claims the recursion's answer must give it.
+
+    The NaN-sign class: Triangle::intersect takes f32::is_sign_positive of values that can be NaN (triangle.rs:91-102: a NaN
+    ray component, n1 / n2 = inf or NaN where |n|^2 underflows, inf - inf).  The sign bit of a NaN that an operation made
+    or passed on is unspecified (IEEE 754; Rust's own docs call the result non-portable): x86 SSE makes negative default
+    NaNs, gfx950 positive ones, so on such rays the reference's verdict depends on the CPU it runs on.  The oracle marks them
+    (pto_trace_nan_flags); they are left out of the comparison, counted, and must still come back as a valid answer."""
+    from tests import fuzz_scenes
+    arr2, tiny, rays = fuzz_scenes.underflow_scene_and_rays(np.random.default_rng(5))
+    n, t = rays.size, arr2.triangles
+    want, nan_sign = oracle.trace_nan_flags(oracle.scene(arr2), rays)
+    assert (~np.isfinite(want["t"]) & ~nan_sign).sum() > 100 and nan_sign.sum() > 5000        # Some(inf) results that ARE portable; the class that is not
+    gsc = gpu_ctx.scene(arr2)
+    try:
+        for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY):
+            gpu_ctx.set_traversal(mode)
+            got = gpu_ctx.trace(gsc, rays)
+            # NaN payloads of t / u / v may differ between x86 and gfx950: compare NaN as NaN
+            same = (got["tri"] == want["tri"]) & np.all([(np.isnan(got[k]) & np.isnan(want[k])) | (got[k].view(np.uint32) == want[k].view(np.uint32)) for k in "tuv"], axis=0)
+            bad = np.flatnonzero(~same & ~nan_sign)
+            assert bad.size == 0, (mode, bad[:5], got[bad[:5]], want[bad[:5]], rays[bad[:5]])
+            assert ((got["tri"] == abi.PT_NO_TRIANGLE) | (got["tri"] < t.size)).all()
+            print(f"mode {mode}: {int(nan_sign.sum())} of {n} rays took the sign of a NaN; {int((~same & nan_sign).sum())} of those differ from the x86 oracle")
+    finally:
+        gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)

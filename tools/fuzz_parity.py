@@ -2,7 +2,7 @@
 """Randomised parity sweep, GPU against the CPU oracle (GPU box): random scenes (sizes 1..20000, degenerate and
 duplicated triangles, flat and huge/small extents), random rays (axis-parallel directions, origins on box faces,
 zero components), all traversal modes + the device-built BVH, and small renders with random materials
-(dissolve, emitters, nearest-sampled textures with uv outside [0,1], interpolated vertex normals, random Hosek-Wilkie suns, cameras).  Prints one JSON line; every tree (the reference's, and the device-built one read back with pt_scene_get_bvh) is checked against the CPU restatement walking that same tree: EXACT must agree on every bit; FAST and WIDE may differ only at equal-t ties and, counted separately, where two hits lie within 4 ulp of each other.
+(dissolve, emitters, nearest-sampled textures with uv outside [0,1], interpolated vertex normals, random Hosek-Wilkie suns, cameras).  Prints one JSON line; every tree (the reference's, and the device-built one read back with pt_scene_get_bvh) is checked against the CPU restatement walking that same tree: EXACT (the default) and REPLAY must agree on every bit; MIN_T may differ only at equal-t ties and, counted separately, where two hits lie within 4 ulp of each other.
 usage: tools/fuzz_parity.py [--seeds N]"""
 import argparse
 import json
@@ -27,7 +27,8 @@ torch.cuda.init()
 ctx, o = core.Context(0), Oracle()
 f32 = np.float32
 stats = {"scenes": 0, "rays": 0, "tie_id_mismatches": {}, "t_mismatches": 0, "within_rounding_mismatches": {}, "tie_examples": [], "lbvh_vs_reference_tree": {"rays": 0, "t_differs": 0, "max_ulps": 0, "id_differs_at_equal_t": 0, "hit_in_one_tree_only": 0}, "images": 0, "pixels_differing": {}, "build_errors_agreed": 0, "failures": []}
-NAMES = {abi.PT_TRAVERSE_WIDE: "wide", abi.PT_TRAVERSE_FAST: "fast", abi.PT_TRAVERSE_EXACT: "exact"}
+NAMES = {abi.PT_TRAVERSE_MIN_T: "min_t", abi.PT_TRAVERSE_REPLAY: "replay", abi.PT_TRAVERSE_EXACT: "exact"}
+EXACT_MODES = (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY)
 
 
 for seed in range(a.first_seed, a.first_seed + a.seeds):
@@ -74,7 +75,7 @@ for seed in range(a.first_seed, a.first_seed + a.seeds):
                     stats["lbvh_vs_reference_tree"]["max_ulps"] = max(stats["lbvh_vs_reference_tree"]["max_ulps"], int(ulps[both].max()))
         else:
             tree_osc, tree_want, tree_want_s = osc, want, want_s
-        for mode in (abi.PT_TRAVERSE_WIDE, abi.PT_TRAVERSE_FAST, abi.PT_TRAVERSE_EXACT):
+        for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_MIN_T, abi.PT_TRAVERSE_REPLAY):
             ctx.set_traversal(mode)
             if tris.size >= 100000:
                 print(f"  lbvh {lbvh} mode {NAMES[mode]}", file=sys.stderr, flush=True)      # big scenes: keep the log moving
@@ -83,12 +84,12 @@ for seed in range(a.first_seed, a.first_seed + a.seeds):
                 key0 = "lbvh/" if lbvh else "reference-tree/"
                 tb = got["t"].view(np.uint32) != ref["t"].view(np.uint32)
                 idm = (got["tri"] != ref["tri"]) & ~tb
-                if mode != abi.PT_TRAVERSE_EXACT and tb.any():
-                    # FAST and WIDE prune a subtree against the best hit of the WHOLE ray (`best_t > entry`), the recursion
+                if mode not in EXACT_MODES and tb.any():
+                    # MIN_T prunes a subtree against the best hit of the WHOLE ray (`best_t > entry`), the recursion
                     # only against the near sibling's result (bvh.rs:285).  In exact arithmetic both keep the minimum; in
                     # binary32 a box's entry distance ((min - o) * inv) can lie an ulp or two ABOVE the distance of the
                     # triangle inside it (Havel-Herout), so a hit from another subtree that close can cut it.  Counted,
-                    # bounded to 4 ulp, not a failure; EXACT has no such case.
+                    # bounded to 4 ulp, not a failure; EXACT and REPLAY have no such case.
                     near = tb & (got["tri"] != abi.PT_NO_TRIANGLE) & (ref["tri"] != abi.PT_NO_TRIANGLE) & \
                         (np.abs(got["t"].view(np.int32).astype(np.int64) - ref["t"].view(np.int32).astype(np.int64)) <= 4)
                     stats["within_rounding_mismatches"][key0 + NAMES[mode]] = stats["within_rounding_mismatches"].get(key0 + NAMES[mode], 0) + int(near.sum())
@@ -99,9 +100,9 @@ for seed in range(a.first_seed, a.first_seed + a.seeds):
                 if idm.any() and len(stats["tie_examples"]) < 8:
                     i = int(np.flatnonzero(idm)[0])
                     stats["tie_examples"].append(f"seed {seed} {key}: ray {i} got {got[i]} want {ref[i]}")
-                if idm.any() and mode == abi.PT_TRAVERSE_EXACT:
+                if idm.any() and mode in EXACT_MODES:
                     i = int(np.flatnonzero(idm)[0])
-                    stats["failures"].append(f"seed {seed} lbvh {lbvh}: EXACT must reproduce ties too: ray {i} got {got[i]} want {ref[i]}")
+                    stats["failures"].append(f"seed {seed} lbvh {lbvh}: {NAMES[mode]} must reproduce ties too: ray {i} got {got[i]} want {ref[i]}")
                 if tb.any():
                     i = int(np.flatnonzero(tb)[0])
                     stats["failures"].append(f"seed {seed} lbvh {lbvh} mode {mode}: ray {i} got {got[i]} want {ref[i]}")
@@ -110,7 +111,7 @@ for seed in range(a.first_seed, a.first_seed + a.seeds):
             fl, sw = float(rng.uniform(20, 120)), float(rng.uniform(10, 50))
             rmode = abi.PT_RENDER_FINAL | (abi.PT_RENDER_NORMALIZE_SKY_DIRECTION if seed % 4 == 2 else 0)
             ref = o.render(tree_osc, 48, 32, 0, 4, 4, seed=seed, sensor_width=sw, focal_length=fl, mode=rmode)
-            for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_WIDE):
+            for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_MIN_T):
                 ctx.set_traversal(mode)
                 img = ctx.render(sc, 48, 32, 0, 4, 4, seed=seed, sensor_width=sw, focal_length=fl, mode=rmode)
                 diff = ~((img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))).all(axis=-1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development aid: time pt_trace_closest_dev on soup-N primary rays in both traversal modes."""
+"""Development aid: time pt_trace_closest_dev on soup-N primary rays in every traversal mode."""
 import argparse
 import ctypes as C
 import sys
@@ -17,7 +17,7 @@ ap.add_argument("--tris", type=int, default=1_000_000)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--fast-only", action="store_true")
+ap.add_argument("--fast-only", action="store_true", help="time the default mode only")
 ap.add_argument("--bounce", action="store_true", help="time incoherent secondary rays (tests/golden/fixture_inputs.bounce_rays) instead of primaries")
 ap.add_argument("--sort", choices=["none", "origin", "origin+octant", "octant"], default="none",
                 help="with --bounce: reorder the secondary rays by a 30-bit Morton key of the origin and/or the direction octant")
@@ -63,8 +63,8 @@ d_rays = torch.from_numpy(rays.view(np.float32).reshape(n, 8)).cuda()
 d_out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
 res = {}
-for mode, name in ((abi.PT_TRAVERSE_FAST, "fast"), (abi.PT_TRAVERSE_WIDE, "wide"), (abi.PT_TRAVERSE_EXACT, "exact")):
-    if a.fast_only and name == "exact":
+for mode, name in ((abi.PT_TRAVERSE_MIN_T, "min_t"), (abi.PT_TRAVERSE_EXACT, "exact"), (abi.PT_TRAVERSE_REPLAY, "replay")):
+    if a.fast_only and name != "exact":
         continue
     ctx.set_traversal(mode)
     ms = []
@@ -95,6 +95,4 @@ if not a.bounce:
           f"device side {ctx.stats().total_ms:.2f} ms, kernels {ctx.stats().trace_ms:.2f} ms in {ctx.stats().trace_launches} launches; "
           f"same hits: {p_out.array.tobytes() == out.tobytes()} crc {__import__('zlib').crc32(out.tobytes())}", flush=True)
 import zlib
-print("fast crc", zlib.crc32(res["fast"].tobytes()), "wide crc", zlib.crc32(res["wide"].tobytes()))
-if not a.fast_only:
-    print("fast==exact ids:", np.array_equal(res["fast"][:, 0], res["exact"][:, 0]), "all:", np.array_equal(res["fast"], res["exact"]))
+print({k: zlib.crc32(v.tobytes()) for k, v in res.items()}, "all equal:", all(np.array_equal(v, res["exact"]) for v in res.values()))
