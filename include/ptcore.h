@@ -215,6 +215,18 @@ void pt_host_free(void* p);
 int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
                          const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out);
 
+/* The same call for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  No counterpart in the reference.  pt_trace_closest_dev grows three device buffers on demand (stack spill
+ * columns, ticket words, the redo list of PT_TRAVERSE_EXACT); this variant runs the same kernels with those buffers carved
+ * out of one fixed device array that every GPU the library runs on holds until the process ends (about 144 MiB), and calls
+ * no hipMalloc / hipFree.  Same results, bit for bit.  Limits, reported as PT_ERR_UNSUPPORTED with a message: at most
+ * PT_NOALLOC_MAX_RAYS rays per call; a BVH so deep that fewer than 8 blocks' stack columns fit is refused (deep scenes run
+ * with a smaller grid than pt_trace_closest_dev uses).  All contexts on one GPU share that GPU's array: one such call at a
+ * time per GPU - calls that overlap in time on one GPU race. */
+#define PT_NOALLOC_MAX_RAYS 4194304u
+int pt_trace_closest_dev_noalloc(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+                                 const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out);
+
 /* Traversal flavour used by both calls above and by pt_render.  All walk the caller's BVH (same boxes, same triangles,
  * same arithmetic per box and per triangle).
  *   EXACT  (default) returns what traverse_recursive returns (bvh.rs:250-338) on every ray, by construction: the same

@@ -46,6 +46,7 @@ def lib():
         "pt_scene_destroy": (None, [vp, vp]),
         "pt_trace_closest": (i32, [vp, vp, vp, vp, u32, vp]),
         "pt_trace_closest_dev": (i32, [vp, vp, vp, vp, u32, vp]),
+        "pt_trace_closest_dev_noalloc": (i32, [vp, vp, vp, vp, u32, vp]),
         "pt_set_traversal": (i32, [vp, u32]),
         "pt_render": (i32, [vp, vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp]),
         "pt_render_dev": (i32, [vp, vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp]),
@@ -76,7 +77,7 @@ EXPORTS = [
     "pt_trace_closest_dev", "pt_set_traversal", "pt_render", "pt_render_dev", "pt_get_stats",
     "pt_scene_get_info", "pt_gen_soup", "pt_gen_primary_rays", "pt_tonemap", "pt_tonemap_dev",
     "pt_scene_file_load", "pt_scene_file_get", "pt_scene_file_free", "pt_scene_create_ex",
-    "pt_host_alloc", "pt_host_free", "pt_scene_get_bvh",
+    "pt_host_alloc", "pt_host_free", "pt_scene_get_bvh", "pt_trace_closest_dev_noalloc",
 ]
 
 
@@ -279,6 +280,10 @@ class Context:
     def trace_dev(self, scene, d_rays, d_start, n, d_out):
         self._check(lib().pt_trace_closest_dev(self.handle, scene.handle, C.c_void_p(d_rays),
                                                C.c_void_p(d_start) if d_start else None, int(n), C.c_void_p(d_out)))
+
+    def trace_dev_noalloc(self, scene, d_rays, d_start, n, d_out):
+        self._check(lib().pt_trace_closest_dev_noalloc(self.handle, scene.handle, C.c_void_p(d_rays),
+                                                       C.c_void_p(d_start) if d_start else None, int(n), C.c_void_p(d_out)))
 
     def render(self, scene, width, height, spp_begin, spp_count, spp_total, seed, mode=abi.PT_RENDER_FINAL,
                sensor_width=36.0, focal_length=50.0):

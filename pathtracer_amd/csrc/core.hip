@@ -99,6 +99,7 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     if ((e = hipHostMalloc((void**)&ctx->h_counters, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bad("hipHostMalloc");
     if ((e = hipMalloc((void**)&ctx->ticket, PTC_TICKET_BYTES)) != hipSuccess) return bad("hipMalloc");
     if ((e = hipMemset(ctx->ticket, 0, PTC_TICKET_BYTES)) != hipSuccess) return bad("hipMemset");
+    if (ptc_noalloc_setup(ctx) != PT_OK) return ptc_fail(nullptr, PT_ERR_HIP, "pt_init: " + ctx->error);
     auto env_u32 = [](const char* name, uint32_t def) {
         const char* v = getenv(name);
         return v ? (uint32_t)strtoul(v, nullptr, 10) : def;

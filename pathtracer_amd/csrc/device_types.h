@@ -150,6 +150,9 @@ inline size_t ptc_spill_depth(const DevSceneView& v, uint32_t mode) {
     return mode == PT_TRAVERSE_REPLAY ? d_replay : mode == PT_TRAVERSE_MIN_T ? d_mint : (d_scoped > d_replay ? d_scoped : d_replay);
 }
 
+// trace_noalloc.hip: resolves this device's address of the fixed scratch array (pt_init, device current)
+int ptc_noalloc_setup(pt_ctx* ctx);
+
 // launch helpers implemented in trace.hip / render.hip
 int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
                         const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out, const ptc_trace_scratch* scratch);
