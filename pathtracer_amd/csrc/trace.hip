@@ -114,6 +114,7 @@ struct RayTickets {
     uint32_t shard, shards_done, shard_len, waves_per_label;
     bool exhausted;                  // every shard's counter ran past its end
     bool first_block;
+    bool all_static;                 // the static first blocks cover the whole batch: no ticket word is ever touched
 
     __device__ __forceinline__ void init(uint32_t n) {
         blk_next = blk_end = 0u;
@@ -124,6 +125,11 @@ struct RayTickets {
         // shard length: a multiple of the static block, so that static and dynamic reservations tile a shard exactly
         shard_len = ((n + PTC_SHARDS * PTC_FIRST - 1u) / (PTC_SHARDS * PTC_FIRST)) * PTC_FIRST;
         waves_per_label = (gridDim.x / PTC_SHARDS) * (PTC_BLOCK / 64u);            // grid is a multiple of PTC_SHARDS
+        // Small batches (the integrator's late iterations, the redo pass): when every shard is covered by the static blocks
+        // a wave is done after its own - walking the shards' ticket words to find them all dry would cost the grid
+        // PTC_SHARDS returning atomics per wave, ~50 000 on words that take ~90 per microsecond each.
+        all_static = shard_len <= waves_per_label * PTC_FIRST;
+        if (n == 0u) exhausted = true;
     }
     // Hands the next rays to the wave's idle lanes (ballot `idle`, `n_idle` of them): true and the batch position
     // `k` for a lane that got one.  Reserves further blocks of `ticket_size` rays as needed.
@@ -135,6 +141,9 @@ struct RayTickets {
                 off = ((blockIdx.x / PTC_SHARDS) * (PTC_BLOCK / 64u) + (threadIdx.x >> 6)) * PTC_FIRST;
                 size = PTC_FIRST;
                 first_block = false;
+            } else if (all_static) {
+                exhausted = true; blk_next = blk_end = 0u;
+                break;
             } else {
                 if (lane == 0u) off = atomicAdd(ticket + shard * 64u, ticket_size);
                 off = __builtin_amdgcn_readfirstlane(off) + waves_per_label * PTC_FIRST;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_mint_persistent(
     st.spill_stride = total_threads;
     st.reset();
     if (sc.n_tris == 0u) {          // empty BVH: every ray misses (bvh.rs:364-368)
-        for (uint32_t k = gtid; k < n; k += total_threads) out[QUEUED ? queue[k] : k] = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
+        for (uint32_t k = gtid; k < n; k += gridDim.x * PTC_BLOCK) out[QUEUED ? queue[k] : k] = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
         return;
     }
 
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_scoped_persistent(
     st.spill_stride = total_threads;
     st.reset();
     if (sc.n_tris == 0u) {          // empty BVH: every ray misses (bvh.rs:364-368)
-        for (uint32_t k = gtid; k < n; k += total_threads) out[QUEUED ? queue[k] : k] = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
+        for (uint32_t k = gtid; k < n; k += gridDim.x * PTC_BLOCK) out[QUEUED ? queue[k] : k] = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
         return;
     }
 
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_replay_persistent(
     st.spill_stride = total_threads;
     st.reset();
     if (sc.n_tris == 0u) {          // empty BVH: every ray misses (bvh.rs:364-368)
-        for (uint32_t k = gtid; k < n; k += total_threads) out[QUEUED ? queue[k] : k] = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
+        for (uint32_t k = gtid; k < n; k += gridDim.x * PTC_BLOCK) out[QUEUED ? queue[k] : k] = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
         return;
     }
     RayTickets tk;
@@ -599,8 +608,11 @@ int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays
             default: PTC_SCOPED(12); break;
         }
 #undef PTC_SCOPED
-        // the redo pass: whatever the scoped kernel listed (usually nothing: the launch then finds a zero count and ends)
+        // the redo pass: whatever the scoped kernel listed - usually nothing, and the launch finds a zero count and ends; its
+        // grid is a quarter of the main one (an empty full-size launch costs ~10 us, and the list is short when it is not
+        // empty; the spill columns are sized for the larger grid)
         next_tickets(tk, tk_next);
+        grid = dim3(std::max(PTC_SHARDS, blocks / 4u / PTC_SHARDS * PTC_SHARDS));
         if (q) PTC_LAUNCH((k_trace_replay_persistent<12, true, true>), redo_list, redo_count);
         else PTC_LAUNCH((k_trace_replay_persistent<12, true, false>), redo_list, redo_count);
     }

@@ -21,6 +21,7 @@ ap.add_argument("--fast-only", action="store_true", help="time the default mode 
 ap.add_argument("--bounce", action="store_true", help="time incoherent secondary rays (tests/golden/fixture_inputs.bounce_rays) instead of primaries")
 ap.add_argument("--sort", choices=["none", "origin", "origin+octant", "octant"], default="none",
                 help="with --bounce: reorder the secondary rays by a 30-bit Morton key of the origin and/or the direction octant")
+ap.add_argument("--device-only", action="store_true", help="skip the host-pointer entry point")
 ap.add_argument("--tile", type=int, default=0, help="reorder rays into TxT pixel tiles")
 a = ap.parse_args()
 
@@ -74,7 +75,7 @@ for mode, name in ((abi.PT_TRAVERSE_MIN_T, "min_t"), (abi.PT_TRAVERSE_EXACT, "ex
     ms = ms[2:]
     res[name] = d_out.cpu().numpy().copy()
     print(f"{name}: {np.mean(ms):.3f} ms (min {np.min(ms):.3f}) -> {n/np.mean(ms)/1e3:.1f} Mrays/s", flush=True)
-if not a.bounce:
+if not a.bounce and not a.device_only:
     ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
     out = np.zeros(n, dtype=abi.HIT)
     ctx.trace(sc, rays, out=out)
