@@ -302,7 +302,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_mint_persistent(
 // distance); the launcher runs the REPLAY kernel over that list next.  Two counters alternate between calls like the
 // ticket words: this launch clears the one the next call uses.
 template <int S, bool QUEUED>
-__global__ __launch_bounds__(PTC_BLOCK) void k_trace_scoped_persistent(
+// (waves_per_eu 4..5: with the default target of 6 the register allocator spills the ray's inverse direction to scratch and
+// reloads it at every record although the kernel then needs 72 VGPRs, which still fit six waves per SIMD)
+__global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_trace_scoped_persistent(
     DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
     uint4* __restrict__ out, uint2* __restrict__ spill, uint32_t total_threads, uint32_t* __restrict__ ticket,
@@ -397,15 +399,13 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_scoped_persistent(
                     break;
                 }
                 const uint2 e = st.pop(ring);
-                if (e.x == PTC_RESTORE) {                          // the enclosing scope's minimum so far
-                    const float parked = __uint_as_float(e.y);
-                    m_cur = parked < m_cur ? parked : m_cur;
-                    continue;
-                }
-                const bool visit = m_cur > __uint_as_float(e.y);   // first_distance > second_child_min (bvh.rs:285)
-                if (e.x & PTC_COMPANION) {                          // the far child's other grandchild lies directly below
+                const float ey = __uint_as_float(e.y);
+                const bool restore = e.x == PTC_RESTORE;                // {RESTORE, the enclosing scope's minimum so far}
+                const bool visit = !restore && m_cur > ey;             // first_distance > second_child_min (bvh.rs:285)
+                if (restore) m_cur = ey < m_cur ? ey : m_cur;
+                if (!restore && (e.x & PTC_COMPANION)) {                // the far child's other grandchild lies directly below
                     const uint2 c = st.pop(ring);
-                    if (visit) {                                    // entering the far child: its far grandchild waits for the near one
+                    if (visit) {                                        // entering the far child: its far grandchild waits for the near one
                         if (m_cur < pt_inf()) { st.push(ring, PTC_RESTORE, __float_as_uint(m_cur)); m_cur = pt_inf(); }
                         st.push(ring, c.x, c.y);
                     }
@@ -543,8 +543,22 @@ int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays
     if (n == 0) return PT_OK;
     if (n > 0xF0000000u) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "more than 0xF0000000 rays in one batch");
     const DevSceneView& v = scene->view;
-    // resident grid: waves_per_simd blocks of 256 per CU at most; fewer when the batch is small
-    uint32_t max_blocks = (uint32_t)ctx->n_cus * ctx->tune_blocks_per_cu;
+    const uint32_t mode = ctx->traversal;
+    // resident grid: waves_per_simd blocks of 256 per CU at most (a persistent kernel must be resident as a whole: a block
+    // that starts only when another ends finds the tickets gone); fewer when the batch is small
+    uint32_t per_cu = ctx->tune_blocks_per_cu;
+    if (mode == PT_TRAVERSE_EXACT) {          // the 16-slot ring is 32 KiB of LDS per block: ask the runtime what fits
+        int& occ = ctx->occ_scoped[ctx->tune_ring == 8u ? 0 : ctx->tune_ring == 16u ? 1 : ctx->tune_ring == 10u ? 3 : 2];
+        if (occ == 0) {
+            const hipError_t e = ctx->tune_ring == 8u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_trace_scoped_persistent<8, false>, PTC_BLOCK, 0)
+                : ctx->tune_ring == 10u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_trace_scoped_persistent<10, false>, PTC_BLOCK, 0)
+                : ctx->tune_ring == 16u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_trace_scoped_persistent<16, false>, PTC_BLOCK, 0)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_trace_scoped_persistent<12, false>, PTC_BLOCK, 0);
+            if (e != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 4; }
+        }
+        per_cu = std::min<uint32_t>(per_cu, (uint32_t)occ);
+    }
+    uint32_t max_blocks = (uint32_t)ctx->n_cus * per_cu;
     if (scratch && scratch->max_blocks && max_blocks > scratch->max_blocks) max_blocks = scratch->max_blocks;
     uint32_t blocks = (n + PTC_BLOCK - 1) / PTC_BLOCK;
     if (blocks > max_blocks) blocks = max_blocks;
@@ -552,7 +566,6 @@ int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays
     // same number of blocks; surplus blocks find nothing to do
     blocks = (blocks + PTC_SHARDS - 1u) / PTC_SHARDS * PTC_SHARDS;
     const uint32_t total_threads = blocks * PTC_BLOCK;
-    const uint32_t mode = ctx->traversal;
     const size_t depth = ptc_spill_depth(v, mode);          // HBM spill columns, entries per thread
     const size_t spill_need = depth * total_threads * sizeof(uint2);
     uint2* spill = nullptr;
@@ -600,10 +613,9 @@ int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays
         redo_parity ^= 1u;
 #define PTC_SCOPED(SS) do { if (q) PTC_LAUNCH((k_trace_scoped_persistent<SS, true>), d_queue, d_count, redo_list, redo_count, redo_count_next); \
                             else PTC_LAUNCH((k_trace_scoped_persistent<SS, false>), d_queue, d_count, redo_list, redo_count, redo_count_next); } while (0)
-        switch (ctx->tune_ring) {
+        switch (ctx->tune_ring) {             // PTC_RING
             case 8:  PTC_SCOPED(8); break;
             case 10: PTC_SCOPED(10); break;
-            case 14: PTC_SCOPED(14); break;
             case 16: PTC_SCOPED(16); break;
             default: PTC_SCOPED(12); break;
         }

@@ -154,49 +154,74 @@ struct PtcWideStep {
     float entry_l, entry_r;
 };
 
+// minNum / maxNum on values that are results of arithmetic (never signalling NaNs).  On the device these are the bare
+// v_min_f32 / v_max_f32 (IEEE mode: the non-NaN operand wins): written as asm because the compiler otherwise puts a
+// canonicalising `v_max_f32 x, x, x` in front of every operand it cannot prove quiet - 24 of them per wide record.
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_HD float ptc_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PT_HD float ptc_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+PT_HD float ptc_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+PT_HD float ptc_max3_0(float a, float b) { float r; asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+PT_HD float ptc_min(float a, float b) { return pt_fmin(a, b); }
+PT_HD float ptc_max(float a, float b) { return pt_fmax(a, b); }
+PT_HD float ptc_min3(float a, float b, float c) { return pt_fmin(pt_fmin(a, b), c); }
+PT_HD float ptc_max3_0(float a, float b) { return pt_fmax(pt_fmax(a, b), 0.0f); }
+#endif
+// bvh.rs:394-405 on per-axis (near, far) pairs: tmin = max(max(max(nx, ny), nz), 0), tmax = min(min(fx, fy), fz)
+PT_HD bool ptc_close(float nx, float fx, float ny, float fy, float nz, float fz, float& tmin_out) {
+    const float tmin = ptc_max3_0(ptc_max(nx, ny), nz);
+    const float tmax = ptc_min3(fx, fy, fz);
+    tmin_out = tmin;
+    return tmax >= tmin;
+}
+
 template <class F4>
 PT_HD void ptc_wide_step(const DRay& r, F4 lox, F4 loy, F4 loz, F4 hix, F4 hiy, F4 hiz, F4 rw, PtcWideStep& s) {
     const PtcPair ax = ptc_slab_axis2(lox.x, lox.y, hix.x, hix.y, r.ox, r.ix), bx = ptc_slab_axis2(lox.z, lox.w, hix.z, hix.w, r.ox, r.ix);
     const PtcPair ay = ptc_slab_axis2(loy.x, loy.y, hiy.x, hiy.y, r.oy, r.iy), by = ptc_slab_axis2(loy.z, loy.w, hiy.z, hiy.w, r.oy, r.iy);
     const PtcPair az = ptc_slab_axis2(loz.x, loz.y, hiz.x, hiz.y, r.oz, r.iz), bz = ptc_slab_axis2(loz.z, loz.w, hiz.z, hiz.w, r.oz, r.iz);
     // per-axis (near, far) of the four slots
-    const float nx0 = pt_fmin(ax.t1.x, ax.t2.x), fx0 = pt_fmax(ax.t1.x, ax.t2.x), nx1 = pt_fmin(ax.t1.y, ax.t2.y), fx1 = pt_fmax(ax.t1.y, ax.t2.y);
-    const float nx2 = pt_fmin(bx.t1.x, bx.t2.x), fx2 = pt_fmax(bx.t1.x, bx.t2.x), nx3 = pt_fmin(bx.t1.y, bx.t2.y), fx3 = pt_fmax(bx.t1.y, bx.t2.y);
-    const float ny0 = pt_fmin(ay.t1.x, ay.t2.x), fy0 = pt_fmax(ay.t1.x, ay.t2.x), ny1 = pt_fmin(ay.t1.y, ay.t2.y), fy1 = pt_fmax(ay.t1.y, ay.t2.y);
-    const float ny2 = pt_fmin(by.t1.x, by.t2.x), fy2 = pt_fmax(by.t1.x, by.t2.x), ny3 = pt_fmin(by.t1.y, by.t2.y), fy3 = pt_fmax(by.t1.y, by.t2.y);
-    const float nz0 = pt_fmin(az.t1.x, az.t2.x), fz0 = pt_fmax(az.t1.x, az.t2.x), nz1 = pt_fmin(az.t1.y, az.t2.y), fz1 = pt_fmax(az.t1.y, az.t2.y);
-    const float nz2 = pt_fmin(bz.t1.x, bz.t2.x), fz2 = pt_fmax(bz.t1.x, bz.t2.x), nz3 = pt_fmin(bz.t1.y, bz.t2.y), fz3 = pt_fmax(bz.t1.y, bz.t2.y);
+    const float nx0 = ptc_min(ax.t1.x, ax.t2.x), fx0 = ptc_max(ax.t1.x, ax.t2.x), nx1 = ptc_min(ax.t1.y, ax.t2.y), fx1 = ptc_max(ax.t1.y, ax.t2.y);
+    const float nx2 = ptc_min(bx.t1.x, bx.t2.x), fx2 = ptc_max(bx.t1.x, bx.t2.x), nx3 = ptc_min(bx.t1.y, bx.t2.y), fx3 = ptc_max(bx.t1.y, bx.t2.y);
+    const float ny0 = ptc_min(ay.t1.x, ay.t2.x), fy0 = ptc_max(ay.t1.x, ay.t2.x), ny1 = ptc_min(ay.t1.y, ay.t2.y), fy1 = ptc_max(ay.t1.y, ay.t2.y);
+    const float ny2 = ptc_min(by.t1.x, by.t2.x), fy2 = ptc_max(by.t1.x, by.t2.x), ny3 = ptc_min(by.t1.y, by.t2.y), fy3 = ptc_max(by.t1.y, by.t2.y);
+    const float nz0 = ptc_min(az.t1.x, az.t2.x), fz0 = ptc_max(az.t1.x, az.t2.x), nz1 = ptc_min(az.t1.y, az.t2.y), fz1 = ptc_max(az.t1.y, az.t2.y);
+    const float nz2 = ptc_min(bz.t1.x, bz.t2.x), fz2 = ptc_max(bz.t1.x, bz.t2.x), nz3 = ptc_min(bz.t1.y, bz.t2.y), fz3 = ptc_max(bz.t1.y, bz.t2.y);
     float k0, k1, k2, k3, kR, kL;
-    const bool h0 = ptc_slab_close_nf(nx0, fx0, ny0, fy0, nz0, fz0, k0);
-    const bool h1 = ptc_slab_close_nf(nx1, fx1, ny1, fy1, nz1, fz1, k1);
-    const bool h2 = ptc_slab_close_nf(nx2, fx2, ny2, fy2, nz2, fz2, k2);
-    const bool h3 = ptc_slab_close_nf(nx3, fx3, ny3, fy3, nz3, fz3, k3);
+    const bool h0 = ptc_close(nx0, fx0, ny0, fy0, nz0, fz0, k0);
+    const bool h1 = ptc_close(nx1, fx1, ny1, fy1, nz1, fz1, k1);
+    const bool h2 = ptc_close(nx2, fx2, ny2, fy2, nz2, fz2, k2);
+    const bool h3 = ptc_close(nx3, fx3, ny3, fy3, nz3, fz3, k3);
     // the children's own boxes (joins of their slots), bvh.rs:260-261 at X
-    const bool hR = ptc_slab_close_nf(pt_fmin(nx0, nx1), pt_fmax(fx0, fx1), pt_fmin(ny0, ny1), pt_fmax(fy0, fy1),
-                                      pt_fmin(nz0, nz1), pt_fmax(fz0, fz1), kR);
-    const bool hL = ptc_slab_close_nf(pt_fmin(nx2, nx3), pt_fmax(fx2, fx3), pt_fmin(ny2, ny3), pt_fmax(fy2, fy3),
-                                      pt_fmin(nz2, nz3), pt_fmax(fz2, fz3), kL);
+    const bool hR = ptc_close(ptc_min(nx0, nx1), ptc_max(fx0, fx1), ptc_min(ny0, ny1), ptc_max(fy0, fy1),
+                              ptc_min(nz0, nz1), ptc_max(fz0, fz1), kR);
+    const bool hL = ptc_close(ptc_min(nx2, nx3), ptc_max(fx2, fx3), ptc_min(ny2, ny3), ptc_max(fy2, fy3),
+                              ptc_min(nz2, nz3), ptc_max(fz2, fz3), kL);
     const uint32_t r0 = pt_f2u(rw.x), r1 = pt_f2u(rw.y), r2 = pt_f2u(rw.z), r3 = pt_f2u(rw.w);
-    // inside each child: left = the odd slot, right = the even one; left first iff l_min < r_min (bvh.rs:266)
+    // inside each child: left = the odd slot, right = the even one; left first iff l_min < r_min (bvh.rs:266).
+    // (conditions are kept as boolean algebra, not as selects between booleans: lane masks stay in scalar registers)
     const bool Rl = h1 && (k1 < k0 || !h0), Ll = h3 && (k3 < k2 || !h2);
     const uint32_t Rnear = Rl ? r1 : r0, Rfar = Rl ? r0 : r1, Lnear = Ll ? r3 : r2, Lfar = Ll ? r2 : r3;
     const float Rfar_e = Rl ? k0 : k1, Lfar_e = Ll ? k2 : k3;
     const bool Rboth = h0 && h1, Lboth = h2 && h3, Rany = h0 || h1, Lany = h2 || h3;
     // at X
-    const bool both = hL && hR;
+    const bool both = hL && hR, any = hL || hR;
     const bool nearL = hL && (kL < kR || !hR);
-    const bool Nany = nearL ? Lany : Rany, Nboth = nearL ? Lboth : Rboth;
-    const bool Fany = nearL ? Rany : Lany, Fboth = nearL ? Rboth : Lboth;
+    const bool Nany = (nearL && Lany) || (!nearL && Rany), Nboth = (nearL && Lboth) || (!nearL && Rboth);
+    const bool Fany = (nearL && Rany) || (!nearL && Lany), Fboth = (nearL && Rboth) || (!nearL && Lboth);
     s.v0 = both && Fboth;
     s.ref0 = nearL ? Rfar : Lfar;
     s.e0 = nearL ? Rfar_e : Lfar_e;
     s.v1 = both && Fany;
-    s.ref1 = (nearL ? Rnear : Lnear) | (Fboth ? PTC_COMPANION : 0u);
+    const uint32_t fnear = nearL ? Rnear : Lnear;
+    s.ref1 = Fboth ? (fnear | PTC_COMPANION) : fnear;
     s.e1 = nearL ? kR : kL;
-    s.v2 = (hL || hR) && Nboth;
+    s.v2 = any && Nboth;
     s.ref2 = nearL ? Lfar : Rfar;
     s.e2 = nearL ? Lfar_e : Rfar_e;
-    s.cur = ((hL || hR) && Nany) ? (nearL ? Lnear : Rnear) : PTC_IDLE;
+    const uint32_t nnear = nearL ? Lnear : Rnear;
+    s.cur = (any && Nany) ? nnear : PTC_IDLE;
     s.hit_l = hL; s.hit_r = hR; s.entry_l = kL; s.entry_r = kR;
 }
 

@@ -84,14 +84,15 @@ extern "C" {
 // out[i] = the scoped traversal's hit of ray i; flagged[i] = 1 where the kernel hands the ray to the replay kernel instead
 // (irregular ray, or a triangle hit at a non-finite distance) - out[i] is then meaningless.
 // stats: [0] records whose derived child boxes differ from the direct slab test of the node's stored boxes (must stay 0),
-//        [1] deepest stack, [2] wide records visited, [3] triangle tests, [4] RESTORE entries pushed
+//        [1] deepest stack, [2] wide records visited, [3] triangle tests, [4] RESTORE entries pushed,
+//        [5] entries pushed (RESTOREs included), [6] popped entries that were entered, [7] loop trips (record + leaf + pops of one lane)
 int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triangle* tris, uint32_t n_tris,
-                     const pt_ray* rays, const uint32_t* start, uint64_t n, pt_hit* out, uint8_t* flagged, uint64_t stats[5]) {
+                     const pt_ray* rays, const uint32_t* start, uint64_t n, pt_hit* out, uint8_t* flagged, uint64_t stats[8]) {
     std::vector<F4> rec((size_t)n_tris * 3);
     for (uint32_t i = 0; i < n_tris; ++i) precompute(tris[i], &rec[(size_t)i * 3]);
     std::vector<Wide> wide(n_nodes);
     for (uint32_t i = 0; i < n_nodes; ++i) if (!nodes[i].is_leaf) wide[i] = make_wide(nodes, i);
-    for (int k = 0; k < 5; ++k) stats[k] = 0;
+    for (int k = 0; k < 8; ++k) stats[k] = 0;
     const float INF = std::numeric_limits<float>::infinity();
     std::vector<Entry> st;
     for (uint64_t i = 0; i < n; ++i) {
@@ -107,12 +108,14 @@ int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triang
         uint32_t cur = nodes[0].is_leaf ? (PTC_LEAF_BIT | nodes[0].shape_index) : 0u;
         st.clear();
         auto push = [&](uint32_t ref, float e) {
-            if (m_cur != INF) { st.push_back({PTC_RESTORE, m_cur}); m_cur = INF; stats[4] += 1; }
+            if (m_cur != INF) { st.push_back({PTC_RESTORE, m_cur}); m_cur = INF; stats[4] += 1; stats[5] += 1; }
             st.push_back({ref, e});
+            stats[5] += 1;
             if (st.size() > stats[1]) stats[1] = st.size();
         };
         bool alive = true;
         while (alive) {
+            stats[7] += 1;
             if (!(cur & PTC_LEAF_BIT)) {
                 const Wide& w = wide[cur];
                 stats[2] += 1;
@@ -157,7 +160,7 @@ int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triang
                     st.pop_back();
                     if (visit) push(c.ref, c.e);
                 }
-                if (visit) cur = e.ref & ~PTC_COMPANION;
+                if (visit) { cur = e.ref & ~PTC_COMPANION; stats[6] += 1; }
             }
         }
         if (!flagged[i]) out[i] = pt_hit{best_id, best_id == PT_NO_TRIANGLE ? 0.0f : best_t, best_u, best_v};

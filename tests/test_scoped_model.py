@@ -30,7 +30,7 @@ def model():
         nodes = arr.nodes if arr.nodes is not None else np.zeros(0, dtype=abi.BVH_NODE)
         out = np.zeros(rays.size, dtype=abi.HIT)
         flagged = np.zeros(rays.size, dtype=np.uint8)
-        stats = (C.c_uint64 * 5)()
+        stats = (C.c_uint64 * 8)()
         st = None if start is None else np.ascontiguousarray(start, dtype=np.uint32)
         L.ptm_trace_scoped(abi.ptr(nodes), nodes.size, abi.ptr(arr.triangles), arr.triangles.size, abi.ptr(rays), abi.ptr(st),
                            rays.size, abi.ptr(out), abi.ptr(flagged), stats)

@@ -36,7 +36,7 @@ def one(seed):
         w = o.trace(osc, rays, st)
         out = np.zeros(rays.size, dtype=abi.HIT)
         fl = np.zeros(rays.size, dtype=np.uint8)
-        stats = (C.c_uint64 * 5)()
+        stats = (C.c_uint64 * 8)()
         L.ptm_trace_scoped(abi.ptr(nodes), nodes.size, abi.ptr(tris), tris.size, abi.ptr(rays), abi.ptr(st), rays.size,
                            abi.ptr(out), abi.ptr(fl), stats)
         ok = fl == 0
