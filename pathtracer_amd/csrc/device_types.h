@@ -113,7 +113,6 @@ struct pt_ctx {
     uint32_t tune_ticket = 64;           // rays a wave reserves per ticket atomic (after its static first block of 64)
     uint32_t tune_shade_blocks_per_cu = 64; // k_shade grid cap (blocks loop over the queue beyond it)
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the EXACT traversal kernel (8, 12 or 16)
-    int occ_scoped[4] = {0, 0, 0, 0};          // resident blocks per CU of that kernel, by ring size (asked once)
     uint32_t tune_host_chunk = 1u << 20;   // pt_trace_closest: rays per pipelined chunk
     uint32_t tune_pass_paths = 128u << 20; // pt_render: paths in flight per pass (~1.1 KiB of HBM each)
 };

@@ -9,6 +9,7 @@ import sys
 from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
+KERNEL = os.environ.get("PT_PROF_KERNEL", "k_trace_scoped_persistent")      # the dominant kernel of the default traversal
 print(f"# rocprofv3 summary {tag}")
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print(f"## kernel stats ({os.path.relpath(f, out)})")
@@ -29,7 +30,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
                 continue
             for c, v in cs.items():
                 print(f"  {k[:60]:60s} {c:30s} n={len(v):4d} mean={sum(v)/len(v):.6g}")
-                if "k_trace" in k:
+                if KERNEL in k:
                     means[c] = sum(v) / len(v)
                     means["kernel"] = k[k.index("k_trace"):].split("(")[0]
 if "FETCH_SIZE" in means:
@@ -54,10 +55,10 @@ if "FETCH_SIZE" in means:
         t["hbm_bytes_per_launch"] = (2.0 * t["FETCH_SIZE_KB"] + t["WRITE_SIZE_KB"]) * 1024.0
         t["correction"] = "read side doubled (gfx950 FETCH_SIZE tallies 128-B requests at 64 B); Infinity-Cache hits included"
     # what bench.py matches this file against (tools/profile_bench.sh runs bench.py's default workload)
-    t["traversal"] = os.environ.get("PT_PROF_TRAVERSAL", "wide")
+    t["traversal"] = os.environ.get("PT_PROF_TRAVERSAL", "exact")
     t["tris"] = int(os.environ.get("PT_PROF_TRIS", "1000000"))
     t["rays"] = int(os.environ.get("PT_PROF_RAYS", "2073600"))
     t["source"] = (f"profiles/{tag}_summary.txt (rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 2 --no-cpu-baseline "
-                   f"--spectral-spp 0`, one pass per counter group, mean over the launches of the traversal kernel)")
+                   f"--spectral-spp 0 --config4-spp 0`, one pass per counter group, mean over the launches of the traversal kernel)")
     json.dump(t, open(os.path.join(out, f"traffic_{tag}.json"), "w"), indent=1)
     print("## traffic", json.dumps(t))
