@@ -68,3 +68,11 @@ def sky_probe():
 def checksum(hits):
     """CRC32 over the (tri, t, u, v) records — a checksum the full-size GPU test compares."""
     return zlib.crc32(np.ascontiguousarray(hits).tobytes()) & 0xFFFFFFFF
+
+
+def image_checksum(img):
+    """CRC32 of an XYZW float image's bits with every NaN canonicalised (NaN payloads and signs are not portable)."""
+    a = np.ascontiguousarray(img, dtype=np.float32).copy()
+    u = a.view(np.uint32)
+    u[np.isnan(a)] = np.uint32(0x7FC00000)
+    return zlib.crc32(u.tobytes()) & 0xFFFFFFFF
