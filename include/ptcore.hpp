@@ -233,6 +233,13 @@ public:
         dev_->check(pt_render(dev_->handle(), scene_, &c, begin, count, total, seed, mode, xyzw.data()));
         return xyzw;
     }
+    // the same into a DEVICE buffer of W*H*4 floats (pt_render_dev): what a rank hands to ncclAllReduce without a trip
+    // through host memory (harness/ptrender_mgpu.cpp)
+    void render_range_dev(const Camera& cam, uint32_t begin, uint32_t count, uint32_t total, uint64_t seed, uint32_t mode,
+                          float* d_xyzw) const {
+        const pt_camera c = cam.ffi();
+        dev_->check(pt_render_dev(dev_->handle(), scene_, &c, begin, count, total, seed, mode, d_xyzw));
+    }
 
 private:
     explicit Scene(Device& dev) : dev_(&dev) {}

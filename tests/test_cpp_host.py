@@ -65,3 +65,38 @@ def test_ptrender_harness(gpu_ctx, tmp_path):
     assert np.array_equal(pfm, img[..., :3])
     bad = subprocess.run([exe, str(tmp_path / "absent.toml"), out], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "cannot open" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_ptrender_mgpu_single_rank_equals_ptrender(tmp_path):
+    """harness/ptrender_mgpu: the sample-split render from a compiled host - rank processes forked before any GPU call,
+    ncclCommInitRank, PT_RENDER_SUM into HBM, ncclAllReduce(ncclFloat, ncclSum), finalize.  With one rank (all this box has)
+    the image must be ptrender's bit for bit; more ranks than GPUs is an error, not a hang.  Unmeasured at N > 1."""
+    import json
+    root = os.path.dirname(HERE)
+    for exe in ("ptrender", "ptrender_mgpu"):
+        if not os.path.exists(os.path.join(root, "harness", exe)):
+            subprocess.check_call(["make", "-C", os.path.join(root, "harness")])
+    scene = os.path.join(root, "examples", "cornell", "scene.toml")
+    a, b = str(tmp_path / "one"), str(tmp_path / "mgpu")
+    p = subprocess.run([os.path.join(root, "harness", "ptrender"), scene, a, "--spp", "6", "--seed", "9"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    q = subprocess.run([os.path.join(root, "harness", "ptrender_mgpu"), scene, b, "--gpus", "1", "--spp", "6", "--seed", "9"],
+                       capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stdout + q.stderr
+    line = json.loads(q.stdout.strip().splitlines()[-1])
+    assert line["gpus"] == 1 and line["spp"] == 6 and line["allreduce_bytes"] == 512 * 512 * 16 and line["spp_per_s"] > 0
+    assert open(a + ".pfm", "rb").read() == open(b + ".pfm", "rb").read()
+    import torch
+    if torch.cuda.device_count() == 1:
+        r = subprocess.run([os.path.join(root, "harness", "ptrender_mgpu"), scene, b, "--gpus", "2", "--spp", "6"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "one rank per GPU" in r.stderr
+
+
+def test_ptrender_mgpu_usage():
+    root = os.path.dirname(HERE)
+    exe = os.path.join(root, "harness", "ptrender_mgpu")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "harness"), "ptrender_mgpu"])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=30)
+    assert p.returncode == 2 and "usage" in p.stderr
