@@ -68,7 +68,7 @@ extern "C" const char* pt_last_error(const pt_ctx* ctx) {
     return g_init_error.c_str();
 }
 
-extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
+static int pt_init_body(const int* device_ids, int n, pt_ctx** out) {
     if (!out) return ptc_fail(nullptr, PT_ERR_INVALID, "pt_init: out is NULL");
     *out = nullptr;
     if (n != 1) return ptc_fail(nullptr, PT_ERR_INVALID, "pt_init: one context drives exactly one GPU (n must be 1)");
@@ -115,6 +115,10 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     guard.p = nullptr;
     *out = ctx;
     return PT_OK;
+}
+
+extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
+    return ptc_guard(nullptr, "pt_init", [&] { return pt_init_body(device_ids, n, out); });
 }
 
 extern "C" void pt_shutdown(pt_ctx* ctx) {
@@ -205,7 +209,7 @@ extern "C" int pt_scene_create(pt_ctx* ctx, const pt_scene_desc* d, pt_scene** o
     return pt_scene_create_ex(ctx, d, 0u, out);
 }
 
-extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t flags, pt_scene** out) {
+static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t flags, pt_scene** out) {
     if (!ctx) return PT_ERR_INVALID;
     if (!d || !out) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: NULL argument");
     *out = nullptr;
@@ -503,10 +507,14 @@ extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t 
     return PT_OK;
 }
 
+extern "C" int pt_scene_create_ex(pt_ctx* ctx, const pt_scene_desc* d, uint32_t flags, pt_scene** out) {
+    return ptc_guard(ctx, "pt_scene_create_ex", [&] { return pt_scene_create_ex_body(ctx, d, flags, out); });
+}
+
 // The scene's binary tree back in the reference's form (enum BVHNode, bvh.rs:123-127, in `BVH.nodes` order: preorder,
 // leaves as entries of their own).  For a scene made from the caller's nodes this is the caller's vector again; for a
 // device-built tree (PT_SCENE_BUILD_LBVH) it is what a host needs to hold that tree as a `BVH { nodes }` of its own.
-extern "C" int pt_scene_get_bvh(pt_ctx* ctx, const pt_scene* scene, pt_bvh_node* nodes_out, uint32_t capacity,
+static int pt_scene_get_bvh_body(pt_ctx* ctx, const pt_scene* scene, pt_bvh_node* nodes_out, uint32_t capacity,
                                 uint32_t* n_nodes_out) {
     if (!ctx) return PT_ERR_INVALID;
     if (!scene || !n_nodes_out) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_get_bvh: NULL argument");
@@ -551,9 +559,14 @@ extern "C" int pt_scene_get_bvh(pt_ctx* ctx, const pt_scene* scene, pt_bvh_node*
     return PT_OK;
 }
 
+extern "C" int pt_scene_get_bvh(pt_ctx* ctx, const pt_scene* scene, pt_bvh_node* nodes_out, uint32_t capacity,
+                                uint32_t* n_nodes_out) {
+    return ptc_guard(ctx, "pt_scene_get_bvh", [&] { return pt_scene_get_bvh_body(ctx, scene, nodes_out, capacity, n_nodes_out); });
+}
+
 // ---- seam 2: closest hit ------------------------------------------------------------------------------
 
-extern "C" int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+static int pt_trace_closest_dev_body(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
                                     const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out) {
     if (!ctx) return PT_ERR_INVALID;
     if (!scene || (n && (!d_rays || !d_out))) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest_dev: NULL argument");
@@ -570,6 +583,11 @@ extern "C" int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt
     ctx->stats.trace_ms = ms; ctx->stats.total_ms = ms;
     ctx->stats.trace_rays = n; ctx->stats.trace_launches = 1;
     return PT_OK;
+}
+
+extern "C" int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+                                    const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out) {
+    return ptc_guard(ctx, "pt_trace_closest_dev", [&] { return pt_trace_closest_dev_body(ctx, scene, d_rays, d_start_tri, n, d_out); });
 }
 
 // pinned host memory for callers that want the host-pointer entry points to run at PCIe speed
@@ -633,7 +651,7 @@ static int trace_closest_host(pt_ctx* ctx, const pt_scene* scene, const pt_ray* 
     return PT_OK;
 }
 
-extern "C" int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
+static int pt_trace_closest_body(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
                                 const uint32_t* start_tri, uint32_t n, pt_hit* out) {
     if (!ctx) return PT_ERR_INVALID;
     if (!scene || (n && (!rays || !out))) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest: NULL argument");
@@ -644,4 +662,9 @@ extern "C" int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray
         (void)hipStreamSynchronize(ctx->copy_in); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->copy_out);
     }
     return rc;
+}
+
+extern "C" int pt_trace_closest(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays,
+                                const uint32_t* start_tri, uint32_t n, pt_hit* out) {
+    return ptc_guard(ctx, "pt_trace_closest", [&] { return pt_trace_closest_body(ctx, scene, rays, start_tri, n, out); });
 }

@@ -123,6 +123,8 @@ int ptc_reserve(pt_ctx* ctx, void** buf, size_t* have, size_t need, const char* 
 // records ctx->trace_ev[i] on the context's stream, creating events up to i on first use
 int ptc_timed_event(pt_ctx* ctx, size_t i);
 
+#include "guard.h"
+
 #define PTC_HIP(ctx, call)                                            \
     do {                                                              \
         int _rc = ptc_hip((ctx), (call), #call);                      \

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/ptcore.h"
+#include "guard.h"
 #include "../../include/pt_math.h"
 
 namespace {
@@ -203,7 +204,7 @@ struct Builder {
 
 }  // namespace
 
-extern "C" int pt_bvh_build(const pt_triangle* triangles, uint32_t n, pt_bvh_node* nodes_out,
+static int pt_bvh_build_body(const pt_triangle* triangles, uint32_t n, pt_bvh_node* nodes_out,
                             uint32_t* n_nodes_out) {
     if (n_nodes_out) *n_nodes_out = 0;
     if (n == 0) return PT_OK;                                                               // bvh.rs:353-355
@@ -241,4 +242,9 @@ extern "C" int pt_bvh_build(const pt_triangle* triangles, uint32_t n, pt_bvh_nod
     }
     if (n_nodes_out) *n_nodes_out = 2 * n - 1;
     return b.error.load();
+}
+
+extern "C" int pt_bvh_build(const pt_triangle* triangles, uint32_t n, pt_bvh_node* nodes_out,
+                            uint32_t* n_nodes_out) {
+    return ptc_noexcept_code([&] { return pt_bvh_build_body(triangles, n, nodes_out, n_nodes_out); });
 }

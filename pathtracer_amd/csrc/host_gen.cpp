@@ -4,9 +4,10 @@
 #include <cstring>
 
 #include "../../include/ptcore.h"
+#include "guard.h"
 #include "../../include/pt_rng.h"
 
-extern "C" int pt_gen_soup(uint64_t seed, uint32_t n, const float lo[3], const float hi[3],
+static int pt_gen_soup_body(uint64_t seed, uint32_t n, const float lo[3], const float hi[3],
                            float edge_scale, float log_scale_hi, uint32_t n_material_cycle,
                            pt_triangle* out) {
     if (!lo || !hi || (!out && n) || !(edge_scale > 0.0f)) return PT_ERR_INVALID;
@@ -30,8 +31,14 @@ extern "C" int pt_gen_soup(uint64_t seed, uint32_t n, const float lo[3], const f
     return PT_OK;
 }
 
+extern "C" int pt_gen_soup(uint64_t seed, uint32_t n, const float lo[3], const float hi[3],
+                           float edge_scale, float log_scale_hi, uint32_t n_material_cycle,
+                           pt_triangle* out) {
+    return ptc_noexcept_code([&] { return pt_gen_soup_body(seed, n, lo, hi, edge_scale, log_scale_hi, n_material_cycle, out); });
+}
+
 // Camera::new + generate_ray at pixel centres (camera.rs:11-28), row-major x + y*W.
-extern "C" int pt_gen_primary_rays(const pt_camera* cam, pt_ray* out) {
+static int pt_gen_primary_rays_body(const pt_camera* cam, pt_ray* out) {
     if (!cam || !out || cam->width == 0 || cam->height == 0) return PT_ERR_INVALID;
     const float w = (float)cam->width, h = (float)cam->height;
     const float sx = 1.0f / (w + 1.0f), sy = 1.0f / (h + 1.0f);
@@ -45,4 +52,8 @@ extern "C" int pt_gen_primary_rays(const pt_camera* cam, pt_ray* out) {
             r.d[2] = -cam->focal_length;
         }
     return PT_OK;
+}
+
+extern "C" int pt_gen_primary_rays(const pt_camera* cam, pt_ray* out) {
+    return ptc_noexcept_code([&] { return pt_gen_primary_rays_body(cam, out); });
 }

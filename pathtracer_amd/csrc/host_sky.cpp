@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "../../include/ptcore.h"
+#include "guard.h"
 #include "../../include/pt_math.h"
 #include "tables.h"
 
@@ -63,7 +64,7 @@ inline void xform_dir(const float* m, const float v[3], float out[3]) {
 
 }  // namespace
 
-extern "C" int pt_sky_hosek_wilkie(float turbidity, float albedo, const float zenith[3],
+static int pt_sky_hosek_wilkie_body(float turbidity, float albedo, const float zenith[3],
                                    const float sun[3], const float* camera_transform, pt_sky* out) {
     if (!zenith || !sun || !out) return PT_ERR_INVALID;
     if (!(turbidity >= 1.0f && turbidity <= 10.0f)) return PT_ERR_INVALID;   // hosek_wilkie.rs:155,351-352
@@ -109,6 +110,11 @@ extern "C" int pt_sky_hosek_wilkie(float turbidity, float albedo, const float ze
         out->radiances[wl] = acc;
     }
     return PT_OK;
+}
+
+extern "C" int pt_sky_hosek_wilkie(float turbidity, float albedo, const float zenith[3],
+                                   const float sun[3], const float* camera_transform, pt_sky* out) {
+    return ptc_noexcept_code([&] { return pt_sky_hosek_wilkie_body(turbidity, albedo, zenith, sun, camera_transform, out); });
 }
 
 extern "C" void pt_sky_d65(float power, pt_sky* out) {

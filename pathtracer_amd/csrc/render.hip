@@ -355,7 +355,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
                        uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* d_xyzw);
 
-extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
+static int pt_render_dev_body(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
                              uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* d_xyzw) {
     if (!ctx) return PT_ERR_INVALID;
     const int rc = render_impl(ctx, scene, cam, spp_begin, spp_count, spp_total, seed, mode, d_xyzw);
@@ -363,6 +363,11 @@ extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera
     // events are quiet before the caller's next call (the error text is kept)
     if (rc != PT_OK && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     return rc;
+}
+
+extern "C" int pt_render_dev(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
+                             uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* d_xyzw) {
+    return ptc_guard(ctx, "pt_render_dev", [&] { return pt_render_dev_body(ctx, scene, cam, spp_begin, spp_count, spp_total, seed, mode, d_xyzw); });
 }
 
 static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
@@ -492,7 +497,7 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
     return PT_OK;
 }
 
-extern "C" int pt_render(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
+static int pt_render_body(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
                          uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* xyzw) {
     if (!ctx) return PT_ERR_INVALID;
     if (!scene || !cam || !xyzw) return ptc_fail(ctx, PT_ERR_INVALID, "pt_render: NULL argument");
@@ -505,4 +510,9 @@ extern "C" int pt_render(pt_ctx* ctx, const pt_scene* scene, const pt_camera* ca
     if (rc != PT_OK) return rc;
     PTC_HIP(ctx, hipMemcpy(xyzw, ctx->io, bytes, hipMemcpyDeviceToHost));
     return PT_OK;
+}
+
+extern "C" int pt_render(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam, uint32_t spp_begin,
+                         uint32_t spp_count, uint32_t spp_total, uint64_t seed, uint32_t mode, float* xyzw) {
+    return ptc_guard(ctx, "pt_render", [&] { return pt_render_body(ctx, scene, cam, spp_begin, spp_count, spp_total, seed, mode, xyzw); });
 }

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_tonemap(const float4* __restrict_
 
 }  // namespace
 
-extern "C" int pt_tonemap_dev(pt_ctx* ctx, const float* d_xyzw, uint32_t width, uint32_t height, float avg_zone,
+static int pt_tonemap_dev_body(pt_ctx* ctx, const float* d_xyzw, uint32_t width, uint32_t height, float avg_zone,
                               float white_zone, uint32_t flags, float* d_rgba, uint8_t* d_bgra8, float stats_out[3]) {
     if (!ctx) return PT_ERR_INVALID;
     if (!d_xyzw || (!d_rgba && !d_bgra8 && !stats_out)) return ptc_fail(ctx, PT_ERR_INVALID, "pt_tonemap_dev: NULL argument");
@@ -105,7 +105,12 @@ extern "C" int pt_tonemap_dev(pt_ctx* ctx, const float* d_xyzw, uint32_t width, 
     return PT_OK;
 }
 
-extern "C" int pt_tonemap(pt_ctx* ctx, const float* xyzw, uint32_t width, uint32_t height, float avg_zone, float white_zone,
+extern "C" int pt_tonemap_dev(pt_ctx* ctx, const float* d_xyzw, uint32_t width, uint32_t height, float avg_zone,
+                              float white_zone, uint32_t flags, float* d_rgba, uint8_t* d_bgra8, float stats_out[3]) {
+    return ptc_guard(ctx, "pt_tonemap_dev", [&] { return pt_tonemap_dev_body(ctx, d_xyzw, width, height, avg_zone, white_zone, flags, d_rgba, d_bgra8, stats_out); });
+}
+
+static int pt_tonemap_body(pt_ctx* ctx, const float* xyzw, uint32_t width, uint32_t height, float avg_zone, float white_zone,
                           uint32_t flags, float* rgba, uint8_t* bgra8, float stats_out[3]) {
     if (!ctx) return PT_ERR_INVALID;
     if (!xyzw) return ptc_fail(ctx, PT_ERR_INVALID, "pt_tonemap: NULL argument");
@@ -123,4 +128,9 @@ extern "C" int pt_tonemap(pt_ctx* ctx, const float* xyzw, uint32_t width, uint32
     if (rgba) PTC_HIP(ctx, hipMemcpy(rgba, base + fb, fb, hipMemcpyDeviceToHost));
     if (bgra8) PTC_HIP(ctx, hipMemcpy(bgra8, base + 2 * fb, bb, hipMemcpyDeviceToHost));
     return PT_OK;
+}
+
+extern "C" int pt_tonemap(pt_ctx* ctx, const float* xyzw, uint32_t width, uint32_t height, float avg_zone, float white_zone,
+                          uint32_t flags, float* rgba, uint8_t* bgra8, float stats_out[3]) {
+    return ptc_guard(ctx, "pt_tonemap", [&] { return pt_tonemap_body(ctx, xyzw, width, height, avg_zone, white_zone, flags, rgba, bgra8, stats_out); });
 }

@@ -53,7 +53,7 @@ int ptc_noalloc_setup(pt_ctx* ctx) {
     return PT_OK;
 }
 
-extern "C" int pt_trace_closest_dev_noalloc(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+static int pt_trace_closest_dev_noalloc_body(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
                                             const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out) {
     if (!ctx) return PT_ERR_INVALID;
     if (!scene || (n && (!d_rays || !d_out))) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest_dev_noalloc: NULL argument");
@@ -94,4 +94,9 @@ extern "C" int pt_trace_closest_dev_noalloc(pt_ctx* ctx, const pt_scene* scene, 
     ctx->stats.trace_ms = ms; ctx->stats.total_ms = ms;
     ctx->stats.trace_rays = n; ctx->stats.trace_launches = 1;
     return PT_OK;
+}
+
+extern "C" int pt_trace_closest_dev_noalloc(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+                                            const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out) {
+    return ptc_guard(ctx, "pt_trace_closest_dev_noalloc", [&] { return pt_trace_closest_dev_noalloc_body(ctx, scene, d_rays, d_start_tri, n, d_out); });
 }

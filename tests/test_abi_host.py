@@ -239,3 +239,33 @@ def test_bvh_build_randomised_against_the_recursive_restatement(oracle):
         assert nodes.tobytes() == oracle.scene(arr).nodes().tobytes(), f"seed {seed}, {n} triangles"
         built += 1
     assert built >= 40
+
+
+def test_allocation_failure_is_an_error_code_not_an_unwind():
+    """include/ptcore.h: nothing throws or aborts across the boundary.  A child process caps its address space just above
+    what it already holds and calls pt_bvh_build on 2 M triangles: the builder's own vectors (about 90 MB) cannot be had,
+    std::bad_alloc is caught at the entry point (csrc/guard.h) and PT_ERR_NOMEM comes back; the process lives on and a small
+    build still works afterwards."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from pathtracer_amd import abi, core
+n = 2_000_000
+tris = core.gen_soup(1, n, (-1, -1, -4), (1, 1, -2), 0.02, 0.0, 8)
+nodes = np.zeros(2 * n - 1, dtype=abi.BVH_NODE)
+small = core.gen_soup(2, 1000, (-1, -1, -4), (1, 1, -2), 0.02, 0.0, 8)
+vm = int(open("/proc/self/statm").read().split()[0]) * resource.getpagesize()
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+resource.setrlimit(resource.RLIMIT_AS, (vm + (24 << 20), hard))
+cnt = C.c_uint32(0)
+rc = core.lib().pt_bvh_build(abi.ptr(tris), n, abi.ptr(nodes), C.byref(cnt))
+print("rc", rc)
+resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+print("after", core.bvh_build(small).size)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert f"rc {abi.PT_ERR_NOMEM}" in p.stdout and "after 1999" in p.stdout, p.stdout + p.stderr
