@@ -251,6 +251,7 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
     std::vector<float4> nodes((size_t)n_internal * 4u);
     std::vector<uint32_t> rank_depth(n_internal, 0u);       // depth of internal node by rank (root = 1)
     uint32_t max_depth = 0;
+    bool boxes_ordered = true;
     {
         // depth = internal nodes on the longest root-to-leaf path (bounds the traversal stack)
         std::vector<uint32_t> depth(n_nodes, 0u);
@@ -277,6 +278,8 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
             float4* q = &nodes[(size_t)internal_rank[i] * 4u];
             float lw, rw;
             std::memcpy(&lw, &lref, 4); std::memcpy(&rw, &rref, 4);
+            for (int k = 0; k < 3; ++k)         // an inverted box (never made by BVH::build) rules out the sign-select wide step
+                if (nd.child_l_aabb.min[k] > nd.child_l_aabb.max[k] || nd.child_r_aabb.min[k] > nd.child_r_aabb.max[k]) boxes_ordered = false;
             q[0] = make_float4(nd.child_l_aabb.min[0], nd.child_l_aabb.min[1], nd.child_l_aabb.min[2], lw);
             q[1] = make_float4(nd.child_l_aabb.max[0], nd.child_l_aabb.max[1], nd.child_l_aabb.max[2], rw);
             q[2] = make_float4(nd.child_r_aabb.min[0], nd.child_r_aabb.min[1], nd.child_r_aabb.min[2], 0.0f);
@@ -499,6 +502,7 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
     s->view.n_materials = d->n_materials;
     s->view.max_depth = max_depth;
     s->view.wide_depth = wide_depth;
+    s->view.sign_select_ok = (boxes_ordered && (uint64_t)n_internal * 128u < (1ull << 32)) ? 1u : 0u;      // (n_wide <= n_internal)
     s->view.root_ref = (N == 1) ? (PTC_LEAF_BIT | (lbvh ? 0u : d->nodes[0].shape_index)) : 0u;
     s->info.n_triangles = N;
     s->info.n_internal_nodes = n_internal;

@@ -74,6 +74,8 @@ struct DevSceneView {       // passed to kernels by value
     uint32_t n_tris;
     uint32_t n_materials;
     uint32_t max_depth;
+    uint32_t sign_select_ok;    // every box has min <= max (or is NaN) and the wide array is below 4 GiB: the EXACT kernel may
+                                // load near / far planes by the sign of the ray's inverse direction (trace_step.h)
 };
 
 struct pt_scene {

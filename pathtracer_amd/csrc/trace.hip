@@ -332,6 +332,8 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
     uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE;
     float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
     float m_cur = pt_inf();          // minimum t found since the newest stack entry was pushed (inf: none)
+    bool sign_ok = true;             // this lane's ray allows the sign-select wide step (an idle lane does not object)
+    uint32_t near_x = 0u, near_y = 16u, near_z = 32u;      // byte offsets of its near planes inside a wide record
 
     for (;;) {
         // ---- refill ----
@@ -347,6 +349,8 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                 if (ptc_ray_is_regular(r)) {
                     best_t = pt_inf(); best_u = 0.0f; best_v = 0.0f; best_id = PT_NO_TRIANGLE;
                     m_cur = pt_inf();
+                    sign_ok = ptc_ray_sign_select(r);
+                    near_x = r.ix < 0.0f ? 48u : 0u; near_y = r.iy < 0.0f ? 64u : 16u; near_z = r.iz < 0.0f ? 80u : 32u;
                     st.reset();
                     cur = sc.root_ref;
                     has_ray = true;
@@ -362,10 +366,26 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
         if (has_ray) {
             // ---- phase 1: wide record = bvh.rs:259-325 at a binary node and at the child it enters ----
             if (!(cur & PTC_LEAF_BIT)) {
-                const float4* p = sc.wide + (size_t)cur * 8u;
-                const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5], rw = p[6];
                 PtcWideStep s;
-                ptc_wide_step(r, lox, loy, loz, hix, hiy, hiz, rw, s);
+                // Sign-select form (trace_step.h) when every ray of the wave has a finite, non-zero inverse direction and the
+                // scene allows it: each lane loads the near planes (lo or hi by the sign of its inverse direction) and the far
+                // planes, and the 24 min / max that pick them drop out.  Uniform base + 32-bit lane offset addressing.
+                if (sc.sign_select_ok && __ballot(!sign_ok) == 0ull) {
+                    const char* base = reinterpret_cast<const char*>(sc.wide);
+                    const uint32_t rec = cur * 128u;
+                    const float4 nearx = *reinterpret_cast<const float4*>(base + (rec + near_x));
+                    const float4 neary = *reinterpret_cast<const float4*>(base + (rec + near_y));
+                    const float4 nearz = *reinterpret_cast<const float4*>(base + (rec + near_z));
+                    const float4 farx = *reinterpret_cast<const float4*>(base + (rec + (48u - near_x)));
+                    const float4 fary = *reinterpret_cast<const float4*>(base + (rec + (80u - near_y)));
+                    const float4 farz = *reinterpret_cast<const float4*>(base + (rec + (112u - near_z)));
+                    const float4 rw = *reinterpret_cast<const float4*>(base + (rec + 96u));
+                    ptc_wide_step_sign(r, nearx, neary, nearz, farx, fary, farz, rw, s);
+                } else {
+                    const float4* p = sc.wide + (size_t)cur * 8u;
+                    const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5], rw = p[6];
+                    ptc_wide_step(r, lox, loy, loz, hix, hiy, hiz, rw, s);
+                }
                 // a push opens a scope: a finite m_cur is parked below it (one RESTORE covers all pushes of this visit)
                 if ((s.v0 || s.v1 || s.v2) && m_cur < pt_inf()) { st.push(ring, PTC_RESTORE, __float_as_uint(m_cur)); m_cur = pt_inf(); }
                 if (s.v0) st.push(ring, s.ref0, __float_as_uint(s.e0));
@@ -383,6 +403,7 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                         if (!(pt_fabs(d) < pt_inf())) {          // Some(inf) / Some(NaN): only the frames get those right
                             redo_list[atomicAdd(redo_count, 1u)] = ray_i;
                             has_ray = false;
+                            sign_ok = true;
                         }
                         if (d <= best_t) { best_t = d; best_u = u; best_v = v; best_id = tri; }    // later visit wins a tie (bvh.rs:299-303)
                         m_cur = d < m_cur ? d : m_cur;
@@ -396,6 +417,7 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                     out[ray_i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
                                             __float_as_uint(best_u), __float_as_uint(best_v));
                     has_ray = false;
+                    sign_ok = true;
                     break;
                 }
                 const uint2 e = st.pop(ring);

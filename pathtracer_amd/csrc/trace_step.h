@@ -176,28 +176,25 @@ PT_HD bool ptc_close(float nx, float fx, float ny, float fy, float nz, float fz,
     return tmax >= tmin;
 }
 
+// The decision stage: per-axis (near, far) of the four slots in, stack entries and next reference out.
+struct PtcSlots {
+    float nx0, fx0, nx1, fx1, nx2, fx2, nx3, fx3;
+    float ny0, fy0, ny1, fy1, ny2, fy2, ny3, fy3;
+    float nz0, fz0, nz1, fz1, nz2, fz2, nz3, fz3;
+};
+
 template <class F4>
-PT_HD void ptc_wide_step(const DRay& r, F4 lox, F4 loy, F4 loz, F4 hix, F4 hiy, F4 hiz, F4 rw, PtcWideStep& s) {
-    const PtcPair ax = ptc_slab_axis2(lox.x, lox.y, hix.x, hix.y, r.ox, r.ix), bx = ptc_slab_axis2(lox.z, lox.w, hix.z, hix.w, r.ox, r.ix);
-    const PtcPair ay = ptc_slab_axis2(loy.x, loy.y, hiy.x, hiy.y, r.oy, r.iy), by = ptc_slab_axis2(loy.z, loy.w, hiy.z, hiy.w, r.oy, r.iy);
-    const PtcPair az = ptc_slab_axis2(loz.x, loz.y, hiz.x, hiz.y, r.oz, r.iz), bz = ptc_slab_axis2(loz.z, loz.w, hiz.z, hiz.w, r.oz, r.iz);
-    // per-axis (near, far) of the four slots
-    const float nx0 = ptc_min(ax.t1.x, ax.t2.x), fx0 = ptc_max(ax.t1.x, ax.t2.x), nx1 = ptc_min(ax.t1.y, ax.t2.y), fx1 = ptc_max(ax.t1.y, ax.t2.y);
-    const float nx2 = ptc_min(bx.t1.x, bx.t2.x), fx2 = ptc_max(bx.t1.x, bx.t2.x), nx3 = ptc_min(bx.t1.y, bx.t2.y), fx3 = ptc_max(bx.t1.y, bx.t2.y);
-    const float ny0 = ptc_min(ay.t1.x, ay.t2.x), fy0 = ptc_max(ay.t1.x, ay.t2.x), ny1 = ptc_min(ay.t1.y, ay.t2.y), fy1 = ptc_max(ay.t1.y, ay.t2.y);
-    const float ny2 = ptc_min(by.t1.x, by.t2.x), fy2 = ptc_max(by.t1.x, by.t2.x), ny3 = ptc_min(by.t1.y, by.t2.y), fy3 = ptc_max(by.t1.y, by.t2.y);
-    const float nz0 = ptc_min(az.t1.x, az.t2.x), fz0 = ptc_max(az.t1.x, az.t2.x), nz1 = ptc_min(az.t1.y, az.t2.y), fz1 = ptc_max(az.t1.y, az.t2.y);
-    const float nz2 = ptc_min(bz.t1.x, bz.t2.x), fz2 = ptc_max(bz.t1.x, bz.t2.x), nz3 = ptc_min(bz.t1.y, bz.t2.y), fz3 = ptc_max(bz.t1.y, bz.t2.y);
+PT_HD void ptc_wide_decide(const PtcSlots& q, F4 rw, PtcWideStep& s) {
     float k0, k1, k2, k3, kR, kL;
-    const bool h0 = ptc_close(nx0, fx0, ny0, fy0, nz0, fz0, k0);
-    const bool h1 = ptc_close(nx1, fx1, ny1, fy1, nz1, fz1, k1);
-    const bool h2 = ptc_close(nx2, fx2, ny2, fy2, nz2, fz2, k2);
-    const bool h3 = ptc_close(nx3, fx3, ny3, fy3, nz3, fz3, k3);
+    const bool h0 = ptc_close(q.nx0, q.fx0, q.ny0, q.fy0, q.nz0, q.fz0, k0);
+    const bool h1 = ptc_close(q.nx1, q.fx1, q.ny1, q.fy1, q.nz1, q.fz1, k1);
+    const bool h2 = ptc_close(q.nx2, q.fx2, q.ny2, q.fy2, q.nz2, q.fz2, k2);
+    const bool h3 = ptc_close(q.nx3, q.fx3, q.ny3, q.fy3, q.nz3, q.fz3, k3);
     // the children's own boxes (joins of their slots), bvh.rs:260-261 at X
-    const bool hR = ptc_close(ptc_min(nx0, nx1), ptc_max(fx0, fx1), ptc_min(ny0, ny1), ptc_max(fy0, fy1),
-                              ptc_min(nz0, nz1), ptc_max(fz0, fz1), kR);
-    const bool hL = ptc_close(ptc_min(nx2, nx3), ptc_max(fx2, fx3), ptc_min(ny2, ny3), ptc_max(fy2, fy3),
-                              ptc_min(nz2, nz3), ptc_max(fz2, fz3), kL);
+    const bool hR = ptc_close(ptc_min(q.nx0, q.nx1), ptc_max(q.fx0, q.fx1), ptc_min(q.ny0, q.ny1), ptc_max(q.fy0, q.fy1),
+                              ptc_min(q.nz0, q.nz1), ptc_max(q.fz0, q.fz1), kR);
+    const bool hL = ptc_close(ptc_min(q.nx2, q.nx3), ptc_max(q.fx2, q.fx3), ptc_min(q.ny2, q.ny3), ptc_max(q.fy2, q.fy3),
+                              ptc_min(q.nz2, q.nz3), ptc_max(q.fz2, q.fz3), kL);
     const uint32_t r0 = pt_f2u(rw.x), r1 = pt_f2u(rw.y), r2 = pt_f2u(rw.z), r3 = pt_f2u(rw.w);
     // inside each child: left = the odd slot, right = the even one; left first iff l_min < r_min (bvh.rs:266).
     // (conditions are kept as boolean algebra, not as selects between booleans: lane masks stay in scalar registers)
@@ -223,6 +220,45 @@ PT_HD void ptc_wide_step(const DRay& r, F4 lox, F4 loy, F4 loz, F4 hix, F4 hiy, 
     const uint32_t nnear = nearL ? Lnear : Rnear;
     s.cur = (any && Nany) ? nnear : PTC_IDLE;
     s.hit_l = hL; s.hit_r = hR; s.entry_l = kL; s.entry_r = kR;
+}
+
+// General form: any REGULAR ray.  (near, far) per axis = (minNum, maxNum) of the two plane distances, as bvh.rs:394-401.
+template <class F4>
+PT_HD void ptc_wide_step(const DRay& r, F4 lox, F4 loy, F4 loz, F4 hix, F4 hiy, F4 hiz, F4 rw, PtcWideStep& s) {
+    const PtcPair ax = ptc_slab_axis2(lox.x, lox.y, hix.x, hix.y, r.ox, r.ix), bx = ptc_slab_axis2(lox.z, lox.w, hix.z, hix.w, r.ox, r.ix);
+    const PtcPair ay = ptc_slab_axis2(loy.x, loy.y, hiy.x, hiy.y, r.oy, r.iy), by = ptc_slab_axis2(loy.z, loy.w, hiy.z, hiy.w, r.oy, r.iy);
+    const PtcPair az = ptc_slab_axis2(loz.x, loz.y, hiz.x, hiz.y, r.oz, r.iz), bz = ptc_slab_axis2(loz.z, loz.w, hiz.z, hiz.w, r.oz, r.iz);
+    PtcSlots q;
+    q.nx0 = ptc_min(ax.t1.x, ax.t2.x); q.fx0 = ptc_max(ax.t1.x, ax.t2.x); q.nx1 = ptc_min(ax.t1.y, ax.t2.y); q.fx1 = ptc_max(ax.t1.y, ax.t2.y);
+    q.nx2 = ptc_min(bx.t1.x, bx.t2.x); q.fx2 = ptc_max(bx.t1.x, bx.t2.x); q.nx3 = ptc_min(bx.t1.y, bx.t2.y); q.fx3 = ptc_max(bx.t1.y, bx.t2.y);
+    q.ny0 = ptc_min(ay.t1.x, ay.t2.x); q.fy0 = ptc_max(ay.t1.x, ay.t2.x); q.ny1 = ptc_min(ay.t1.y, ay.t2.y); q.fy1 = ptc_max(ay.t1.y, ay.t2.y);
+    q.ny2 = ptc_min(by.t1.x, by.t2.x); q.fy2 = ptc_max(by.t1.x, by.t2.x); q.ny3 = ptc_min(by.t1.y, by.t2.y); q.fy3 = ptc_max(by.t1.y, by.t2.y);
+    q.nz0 = ptc_min(az.t1.x, az.t2.x); q.fz0 = ptc_max(az.t1.x, az.t2.x); q.nz1 = ptc_min(az.t1.y, az.t2.y); q.fz1 = ptc_max(az.t1.y, az.t2.y);
+    q.nz2 = ptc_min(bz.t1.x, bz.t2.x); q.fz2 = ptc_max(bz.t1.x, bz.t2.x); q.nz3 = ptc_min(bz.t1.y, bz.t2.y); q.fz3 = ptc_max(bz.t1.y, bz.t2.y);
+    ptc_wide_decide(q, rw, s);
+}
+
+// Sign-select form, for a ray whose inverse direction is finite and non-zero on every axis (PTC_RAY_SIGN_SELECT) over boxes
+// with min <= max (every box BVH::build makes; pt_scene_create checks a caller's): t = fl(fl(c - o) * inv) is then monotone
+// in c and never NaN for a finite c, so min(t(lo), t(hi)) IS t(lo) where inv > 0 and t(hi) where inv < 0 - the caller loads
+// the near planes (lo or hi by the sign of inv, per axis) and the far planes and the 24 min / max of the general form drop
+// out.  An empty slot's NaN planes give NaN either way.  Same values bit for bit, so the same decisions;
+// tests/cpp/scoped_model.cpp runs both forms on every record such a ray visits and compares.
+template <class F4>
+PT_HD void ptc_wide_step_sign(const DRay& r, F4 nearx, F4 neary, F4 nearz, F4 farx, F4 fary, F4 farz, F4 rw, PtcWideStep& s) {
+    const PtcPair ax = ptc_slab_axis2(nearx.x, nearx.y, farx.x, farx.y, r.ox, r.ix), bx = ptc_slab_axis2(nearx.z, nearx.w, farx.z, farx.w, r.ox, r.ix);
+    const PtcPair ay = ptc_slab_axis2(neary.x, neary.y, fary.x, fary.y, r.oy, r.iy), by = ptc_slab_axis2(neary.z, neary.w, fary.z, fary.w, r.oy, r.iy);
+    const PtcPair az = ptc_slab_axis2(nearz.x, nearz.y, farz.x, farz.y, r.oz, r.iz), bz = ptc_slab_axis2(nearz.z, nearz.w, farz.z, farz.w, r.oz, r.iz);
+    PtcSlots q;
+    q.nx0 = ax.t1.x; q.fx0 = ax.t2.x; q.nx1 = ax.t1.y; q.fx1 = ax.t2.y; q.nx2 = bx.t1.x; q.fx2 = bx.t2.x; q.nx3 = bx.t1.y; q.fx3 = bx.t2.y;
+    q.ny0 = ay.t1.x; q.fy0 = ay.t2.x; q.ny1 = ay.t1.y; q.fy1 = ay.t2.y; q.ny2 = by.t1.x; q.fy2 = by.t2.x; q.ny3 = by.t1.y; q.fy3 = by.t2.y;
+    q.nz0 = az.t1.x; q.fz0 = az.t2.x; q.nz1 = az.t1.y; q.fz1 = az.t2.y; q.nz2 = bz.t1.x; q.fz2 = bz.t2.x; q.nz3 = bz.t1.y; q.fz3 = bz.t2.y;
+    ptc_wide_decide(q, rw, s);
+}
+// the ray qualifies for the sign-select form: every inverse direction component finite and non-zero
+PT_HD bool ptc_ray_sign_select(const DRay& r) {
+    const float big = pt_inf();
+    return pt_fabs(r.ix) < big && pt_fabs(r.iy) < big && pt_fabs(r.iz) < big && r.ix != 0.0f && r.iy != 0.0f && r.iz != 0.0f;
 }
 
 #endif

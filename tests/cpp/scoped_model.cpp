@@ -83,7 +83,8 @@ extern "C" {
 
 // out[i] = the scoped traversal's hit of ray i; flagged[i] = 1 where the kernel hands the ray to the replay kernel instead
 // (irregular ray, or a triangle hit at a non-finite distance) - out[i] is then meaningless.
-// stats: [0] records whose derived child boxes differ from the direct slab test of the node's stored boxes (must stay 0),
+// stats: [0] records whose derived child boxes differ from the direct slab test of the node's stored boxes, or whose
+//            sign-select form decides differently from the general form (must stay 0),
 //        [1] deepest stack, [2] wide records visited, [3] triangle tests, [4] RESTORE entries pushed,
 //        [5] entries pushed (RESTOREs included), [6] popped entries that were entered, [7] loop trips (record + leaf + pops of one lane)
 int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triangle* tris, uint32_t n_tris,
@@ -102,6 +103,7 @@ int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triang
         const F4 o{rays[i].o[0], rays[i].o[1], rays[i].o[2], 0.0f}, d{rays[i].d[0], rays[i].d[1], rays[i].d[2], 0.0f};
         const DRay r = ptc_make_ray(o, d);
         if (!ptc_ray_is_regular(r)) { flagged[i] = 1; continue; }
+        const bool sign_ok = ptc_ray_sign_select(r);
         const uint32_t skip = start ? start[i] : PT_NO_TRIANGLE;
         float best_t = INF, best_u = 0.0f, best_v = 0.0f, m_cur = INF;
         uint32_t best_id = PT_NO_TRIANGLE;
@@ -121,6 +123,15 @@ int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triang
                 stats[2] += 1;
                 PtcWideStep s;
                 ptc_wide_step(r, w.lox, w.loy, w.loz, w.hix, w.hiy, w.hiz, w.rw, s);
+                if (sign_ok) {   // the sign-select form the kernel uses for such rays: same decisions, bit for bit
+                    PtcWideStep f;
+                    ptc_wide_step_sign(r, r.ix < 0.0f ? w.hix : w.lox, r.iy < 0.0f ? w.hiy : w.loy, r.iz < 0.0f ? w.hiz : w.loz,
+                                       r.ix < 0.0f ? w.lox : w.hix, r.iy < 0.0f ? w.loy : w.hiy, r.iz < 0.0f ? w.loz : w.hiz, w.rw, f);
+                    const bool same = f.cur == s.cur && f.v0 == s.v0 && f.v1 == s.v1 && f.v2 == s.v2 &&
+                                      (!s.v0 || (f.ref0 == s.ref0 && f.e0 == s.e0)) && (!s.v1 || (f.ref1 == s.ref1 && f.e1 == s.e1)) &&
+                                      (!s.v2 || (f.ref2 == s.ref2 && f.e2 == s.e2));
+                    if (!same) stats[0] += 1;
+                }
                 {   // the derived children's boxes against the direct test of the stored ones (bvh.rs:260-261)
                     const pt_bvh_node& x = nodes[cur];
                     float lt = 0.0f, rt = 0.0f;
