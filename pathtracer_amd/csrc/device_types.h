@@ -116,7 +116,9 @@ struct pt_ctx {
     uint32_t tune_shade_blocks_per_cu = 64; // k_shade grid cap (blocks loop over the queue beyond it)
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the EXACT traversal kernel (8, 12 or 16)
     uint32_t tune_host_chunk = 1u << 20;   // pt_trace_closest: rays per pipelined chunk
-    uint32_t tune_pass_paths = 128u << 20; // pt_render: paths in flight per pass (~1.1 KiB of HBM each)
+    uint32_t tune_pass_paths = 128u << 20; // pt_render: paths in flight (~1.1 KiB of HBM each)
+    uint32_t tune_pass_slots = 2;          // pt_render: passes in flight (1..4) of a render that does not fit in one
+    float    tune_admit_frac = 0.25f;      // pt_render: the next pass joins when <= this fraction of a pass's paths is live
 };
 
 int ptc_fail(pt_ctx* ctx, int code, const std::string& msg);

@@ -6,8 +6,13 @@
 //                      from the 3rd vertex, dissolve pass-through, sky on miss, back-to-front fold)
 //   material.rs:255-297  Material::sample (dissolve test, normal, Lambert sphere offset, emission)
 //
-// One PASS renders `spp_pass` consecutive sample indices of every pixel at once: path id
-// p = s_local * (W*H) + pixel.  Per-path state lives in HBM indexed by the path id, packed so that
+// One PASS renders `spp_pass` consecutive sample indices of every pixel at once.  Up to PTC_MAX_SLOTS passes are in
+// flight together, each in its own SLOT of the workspace: path id p = slot * cap + s_local * (W*H) + pixel.  When the
+// live paths of the passes in flight have thinned out, the next pass is generated into a free slot and its paths are
+// appended to the same queue, so that a traversal launch never holds only the thin tail of one pass (the last ten of
+// a pass's ~18 iterations hold < 3 % of its paths and cost a ray's latency each).  A pass is folded into the image
+// when the host learns that its last path has ended, oldest pass first, so every pixel still receives its samples in
+// sample order.  Per-path state lives in HBM indexed by the path id, packed so that
 // every access is a whole 8/16/64-byte record (after a few bounces the live paths are sparse in p,
 // and 4-byte columns would touch one cache line per value); QUEUES hold the ids of live paths.  Each iteration the traversal kernel (trace.hip)
 // extends every queued ray, then the shade kernel consumes the hits, pushes one {weight, emit}
@@ -33,33 +38,39 @@
 #define PTC_SHADE_SPAN 2048u     /* queue entries a k_shade block handles per global queue reservation */
 #define PTC_MAX_VERTS 16        /* ArrayVec<_, 16>, scene.rs:324 */
 #define PTC_MAX_ITERS 1024u     /* scene.rs:328 */
+#define PTC_MAX_SLOTS 4          /* passes in flight */
 
 namespace {
 
 struct PassState {
-    float4*   rays;       // [P][2]  {origin.xyz, bits(start triangle)}, {direction.xyz, hero wavelength offset}:
+    float4*   rays;       // [N][2]  {origin.xyz, bits(start triangle)}, {direction.xyz, hero wavelength offset}:
                           //         pt_ray layout with the two pads in use; trace.hip reads the start from pad0
-    uint4*    hits;       // [P]
-    uint2*    state;      // [P]  {draws consumed so far by the path's stream, len (5 bits) | iterations << 5 (11 bits) |
+    uint4*    hits;       // [N]
+    uint2*    state;      // [N]  {draws consumed so far by the path's stream, len (5 bits) | iterations << 5 (11 bits) |
                           //       emit mask << 16: bit k set = vertex k carries an emission term}
-    float4*   verts;      // weights [16][P][2] then emits [16][P][2]: vertex k of path p = {weight[0..3], weight[4..7]} and
+    float4*   verts;      // weights [16][N][2] then emits [16][N][2]: vertex k of path p = {weight[0..3], weight[4..7]} and
                           //         {emit[0..3], emit[4..7]}, vertex-major so that the lanes of an iteration (k_shade) and the
                           //         neighbouring pixels of a sample (k_accumulate) touch neighbouring 32-byte records; the emit
                           //         record is only written and read where the state's emit mask says so (7 of 8 soup materials
                           //         emit nothing)
-    uint32_t* queue[2];   // [P] each
-    uint32_t* miss_queue; // [P] paths whose ray left the scene; their sky term is evaluated once per pass (k_sky)
-    uint32_t* counts;     // [4]: [0..2] rotating live-path counters (iteration i reads [i%3], fills [(i+1)%3],
-                          //      clears [(i+2)%3]); [3] = length of miss_queue
-    uint32_t  P;          // paths in this pass
+    uint32_t* queue[2];   // [N] each
+    uint32_t* miss_queue; // [N] paths whose ray left the scene since the last k_sky
+    uint32_t* counts;     // [8]: three rotating pairs {live paths, live paths of the watched slot} at [2c], [2c + 1]
+                          //      (iteration i reads pair i%3, fills pair (i+1)%3, clears pair (i+2)%3); [6] = length of miss_queue
+    uint32_t  cap;        // paths per slot
+    uint32_t  N;          // slots * cap: the path id space
     uint32_t  npix;
+    uint32_t  sample_base[PTC_MAX_SLOTS];   // first sample index of the pass in each slot
 };
 
+__device__ __forceinline__ uint32_t slot_of(const PassState& st, uint32_t p) {
+    return (uint32_t)(p >= st.cap) + (uint32_t)(p >= 2u * st.cap) + (uint32_t)(p >= 3u * st.cap);   // cap <= 2^28
+}
 __device__ __forceinline__ float4* weight_ptr(const PassState& st, uint32_t p, uint32_t k) {
-    return st.verts + ((size_t)k * st.P + p) * 2u;
+    return st.verts + ((size_t)k * st.N + p) * 2u;
 }
 __device__ __forceinline__ float4* emit_ptr(const PassState& st, uint32_t p, uint32_t k) {
-    return st.verts + ((size_t)(PTC_MAX_VERTS + k) * st.P + p) * 2u;
+    return st.verts + ((size_t)(PTC_MAX_VERTS + k) * st.N + p) * 2u;
 }
 __device__ __forceinline__ void store_vertex(const PassState& st, uint32_t p, uint32_t k, const float w[PTC_NW],
                                              const float e[PTC_NW], bool has_emit) {
@@ -78,13 +89,16 @@ __device__ __forceinline__ void store_vertex(const PassState& st, uint32_t p, ui
 #define PTC_STATE_PACK(len, iter, emask) ((len) | ((iter) << 5) | ((emask) << 16))
 
 // ---- generate: main.rs:76-89 -----------------------------------------------------------------------
-__global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera cam, uint64_t seed,
-                                                       uint32_t sample_base) {
-    const uint32_t p = blockIdx.x * PTC_BLOCK + threadIdx.x;
-    if (p == 0u) { st.counts[0] = st.P; st.counts[1] = 0u; st.counts[2] = 0u; st.counts[3] = 0u; }
-    if (p >= st.P) return;
-    const uint32_t pixel = p % st.npix;
-    const uint32_t sample = sample_base + p / st.npix;
+// The `n` paths of a new pass go into `slot` and are appended to the queue of the iteration about to be enqueued, behind
+// the survivors already there (counter pair `c`; k_admit then adds n to it - a kernel of its own because every block of
+// this one reads the old length).
+__global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera cam, uint64_t seed, uint32_t slot,
+                                                       uint32_t n, uint32_t c, uint32_t qsel) {
+    const uint32_t j = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t p = slot * st.cap + j;
+    const uint32_t pixel = j % st.npix;
+    const uint32_t sample = st.sample_base[slot] + j / st.npix;
     const uint32_t px = pixel % cam.width, py = pixel / cam.width;
     pt_rng rng;
     pt_rng_init(&rng, seed, pixel, sample, 0u);
@@ -101,7 +115,13 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera 
     st.rays[2u * p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PT_NO_TRIANGLE));
     st.rays[2u * p + 1u] = make_float4(dx, dy, dz, hero);
     st.state[p] = make_uint2(rng.index, 0u);
-    st.queue[0][p] = p;
+    st.queue[qsel][st.counts[2u * c] + j] = p;
+}
+__global__ void k_admit(uint32_t* counts, uint32_t c, uint32_t n, uint32_t watched) {
+    if (threadIdx.x == 0u && blockIdx.x == 0u) {
+        counts[2u * c] += n;
+        if (watched) counts[2u * c + 1u] += n;       // the new pass is the oldest in flight
+    }
 }
 
 // ---- shade: one iteration of the loop body scene.rs:333-368 ------------------------------------------
@@ -113,21 +133,21 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera 
 // queue, or to the miss queue) are collected per block in LDS and appended with ONE global atomic per
 // list and span of PTC_SHADE_SPAN paths.
 __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState st, uint32_t cur, uint32_t cin,
-                                                    uint64_t seed, uint32_t sample_base) {
+                                                    uint64_t seed, uint32_t watch_slot) {
     __shared__ ptc::SpectralLds tab;
     // ids of the paths this block sends on: survivors fill qbuf from the front, misses from the back
     // (they are disjoint subsets of the PTC_SHADE_SPAN paths a block handles per span)
     __shared__ uint32_t qbuf[PTC_SHADE_SPAN];
-    __shared__ uint32_t q_n[2], q_base[2];
-    const uint32_t count = st.counts[cin];
-    uint32_t* const next_count = &st.counts[cin == 2u ? 0u : cin + 1u];
-    if (blockIdx.x == 0u && threadIdx.x == 0u) st.counts[cin == 0u ? 2u : cin - 1u] = 0u;   // the counter the NEXT iteration fills
+    __shared__ uint32_t q_n[3], q_base[2];              // continuing, missed, continuing in the watched slot
+    const uint32_t count = st.counts[2u * cin];
+    uint32_t* const next_count = &st.counts[2u * (cin == 2u ? 0u : cin + 1u)];
+    if (blockIdx.x == 0u && threadIdx.x < 2u) st.counts[2u * (cin == 0u ? 2u : cin - 1u) + threadIdx.x] = 0u;   // the pair the NEXT iteration fills
     if (blockIdx.x * PTC_SHADE_SPAN >= count) return;            // surplus block of an over-sized grid
     ptc::spectral_lds_fill(tab, sc.refl_tab, sc.d65_tab, threadIdx.x, PTC_BLOCK);
     const uint32_t lane = threadIdx.x & 63u;
     // grid-stride over the queue in spans of PTC_SHADE_SPAN entries (trip counts are uniform per block)
     for (uint32_t span0 = blockIdx.x * PTC_SHADE_SPAN; span0 < count; span0 += gridDim.x * PTC_SHADE_SPAN) {
-    if (threadIdx.x < 2u) q_n[threadIdx.x] = 0u;
+    if (threadIdx.x < 3u) q_n[threadIdx.x] = 0u;
     __syncthreads();
     for (uint32_t k0 = span0; k0 < span0 + PTC_SHADE_SPAN && k0 < count; k0 += PTC_BLOCK) {
         const uint32_t k = k0 + threadIdx.x;
@@ -140,7 +160,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
         const bool missed = active && hit.x == PT_NO_TRIANGLE;
         const bool shading = active && !missed;
 
-        bool cont = false, put_vertex = false, put_dir = false, has_emit = false;
+        bool cont = false, put_vertex = false, put_dir = false, has_emit = false, in_watched = false;
         float weight[PTC_NW], emit[PTC_NW];
         float4 new_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), new_d = new_o;
         uint2 new_state = make_uint2(0u, 0u);
@@ -169,7 +189,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
                 v = w0 * s0.w + hu * s1.y + hv * s1.w;
             }
             pt_rng rng;
-            pt_rng_init(&rng, seed, p % st.npix, sample_base + p / st.npix, state.x);
+            const uint32_t slot = slot_of(st, p), j = p - slot * st.cap;
+            in_watched = slot == watch_slot;
+            pt_rng_init(&rng, seed, j % st.npix, st.sample_base[slot] + j / st.npix, state.x);
             float dis = m.dissolve_value;
             if (m.dissolve_img != 0xFFFFFFFFu) {
                 float g, b; const float flat[3] = {dis, dis, dis};
@@ -242,12 +264,15 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
         }
 
         // hand the path on: ballot -> one LDS atomic per wave and list -> slot in the block's buffer
-        const unsigned long long mmask = __ballot(missed), cmask = __ballot(cont);
+        const unsigned long long mmask = __ballot(missed), cmask = __ballot(cont), wmask = __ballot(cont && in_watched);
         const unsigned long long below = (1ull << lane) - 1ull;
         if (cmask != 0ull) {
             const int leader = __ffsll((long long)cmask) - 1;
             uint32_t base = 0u;
-            if ((int)lane == leader) base = atomicAdd(&q_n[0], (uint32_t)__popcll(cmask));
+            if ((int)lane == leader) {
+                base = atomicAdd(&q_n[0], (uint32_t)__popcll(cmask));
+                if (wmask != 0ull) atomicAdd(&q_n[2], (uint32_t)__popcll(wmask));
+            }
             base = __shfl(base, leader);
             if (cont) qbuf[base + (uint32_t)__popcll(cmask & below)] = p;
         }
@@ -272,7 +297,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
     // microsecond chip-wide: one per wave, as this kernel first did, made those atomics its whole run time)
     __syncthreads();
     if (threadIdx.x == 0u && q_n[0] != 0u) q_base[0] = atomicAdd(next_count, q_n[0]);
-    if (threadIdx.x == 64u && q_n[1] != 0u) q_base[1] = atomicAdd(&st.counts[3], q_n[1]);
+    if (threadIdx.x == 64u && q_n[1] != 0u) q_base[1] = atomicAdd(&st.counts[6], q_n[1]);
+    if (threadIdx.x == 128u && q_n[2] != 0u) atomicAdd(next_count + 1, q_n[2]);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < q_n[0]; i += PTC_BLOCK) st.queue[cur ^ 1u][q_base[0] + i] = qbuf[i];
     for (uint32_t i = threadIdx.x; i < q_n[1]; i += PTC_BLOCK) st.miss_queue[q_base[1] + i] = qbuf[PTC_SHADE_SPAN - 1u - i];
@@ -280,9 +306,10 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
     }   // spans
 }
 
-// ---- sky: Scene::evaluate_sky for every path of the pass that left the scene (scene.rs:362-367) ------
+// ---- sky: Scene::evaluate_sky for every path that left the scene since the last k_sky (scene.rs:362-367); the kernel
+// that follows (k_accumulate) empties the list ------
 __global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky* __restrict__ sky, PassState st, uint32_t normalize) {
-    const uint32_t count = st.counts[3];
+    const uint32_t count = st.counts[6];
     for (uint32_t k = blockIdx.x * PTC_BLOCK + threadIdx.x; k < count; k += gridDim.x * PTC_BLOCK) {
         const uint32_t p = st.miss_queue[k];
         const float4 rd = st.rays[2u * p + 1u];
@@ -304,12 +331,13 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky
 }
 
 // ---- accumulate: fold + CMF + pixel sum (scene.rs:371-373, main.rs:93-97) -----------------------------
-__global__ __launch_bounds__(PTC_BLOCK) void k_accumulate(PassState st, uint32_t spp_pass, float4* __restrict__ acc) {
+__global__ __launch_bounds__(PTC_BLOCK) void k_accumulate(PassState st, uint32_t slot, uint32_t spp_pass, float4* __restrict__ acc) {
     const uint32_t pixel = blockIdx.x * PTC_BLOCK + threadIdx.x;
+    if (pixel == 0u) st.counts[6] = 0u;               // the k_sky before this kernel has consumed the miss list
     if (pixel >= st.npix) return;
     float4 a = acc[pixel];
     for (uint32_t s = 0; s < spp_pass; ++s) {
-        const uint32_t p = s * st.npix + pixel;
+        const uint32_t p = slot * st.cap + s * st.npix + pixel;
         const uint32_t sy = st.state[p].y;
         const uint32_t len = PTC_STATE_LEN(sy), emask = PTC_STATE_EMASK(sy);
         const float hero = st.rays[2u * p + 1u].w;
@@ -385,28 +413,39 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
     PTC_HIP(ctx, hipSetDevice(ctx->device));
     ctx->stats = pt_stats{};
 
-    // paths per pass: ctx->tune_pass_paths in flight (1 KiB of vertex column each), whole samples only.  When the
-    // workspace for that does not fit in what is left of HBM the pass is halved until it does (one sample of every
-    // pixel is the floor): smaller passes cost throughput, never the image (samples are independent).
+    // ctx->tune_pass_paths paths in flight (1.1 KiB of HBM each).  A render that fits is ONE pass; a longer one is cut
+    // into passes of whole samples, ctx->tune_pass_slots of them in flight, each 1 / slots of the budget.  When the
+    // workspace does not fit in what is left of HBM the pass is halved until it does (one sample of every pixel is the
+    // floor, then fewer slots): that costs throughput, never the image (samples are independent and each pixel adds its
+    // own in sample order).
+    uint32_t slots = 1u;
     uint32_t spp_pass = (uint32_t)std::max<uint64_t>(1, (uint64_t)ctx->tune_pass_paths / npix);
-    if (spp_pass > spp_count) spp_pass = spp_count ? spp_count : 1u;
+    if (spp_pass >= spp_count) spp_pass = spp_count ? spp_count : 1u;
+    else {
+        slots = std::min<uint32_t>(ctx->tune_pass_slots, PTC_MAX_SLOTS);
+        spp_pass = std::max(1u, spp_pass / slots);
+    }
     size_t o_acc, o_rays, o_hits, o_state, o_q0, o_q1, o_qm, o_cnt, o_verts;
     for (;;) {
-        const uint32_t Pmax = spp_pass * npix;
+        const uint32_t n_pass = spp_count ? (spp_count + spp_pass - 1u) / spp_pass : 1u;
+        slots = std::max(1u, std::min(slots, n_pass));
+        const size_t N = (size_t)slots * spp_pass * npix;
         // ---- carve the workspace -----------------------------------------------------------------
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
         o_acc = carve((size_t)npix * sizeof(float4));
-        o_rays = carve((size_t)Pmax * 2 * sizeof(float4));
-        o_hits = carve((size_t)Pmax * sizeof(uint4));
-        o_state = carve((size_t)Pmax * sizeof(uint2));
-        o_q0 = carve((size_t)Pmax * 4); o_q1 = carve((size_t)Pmax * 4); o_qm = carve((size_t)Pmax * 4);
+        o_rays = carve(N * 2 * sizeof(float4));
+        o_hits = carve(N * sizeof(uint4));
+        o_state = carve(N * sizeof(uint2));
+        o_q0 = carve(N * 4); o_q1 = carve(N * 4); o_qm = carve(N * 4);
         o_cnt = carve(256);
-        o_verts = carve((size_t)Pmax * PTC_MAX_VERTS * 2 * PTC_NW * sizeof(float));
-        const int rc = ptc_reserve(ctx, &ctx->work, &ctx->work_bytes, off, "render workspace");
+        o_verts = carve(N * PTC_MAX_VERTS * 2 * PTC_NW * sizeof(float));
+        int rc = PT_ERR_NOMEM;
+        if (N <= (1ull << 30)) rc = ptc_reserve(ctx, &ctx->work, &ctx->work_bytes, off, "render workspace");
         if (rc == PT_OK) break;
-        if (rc != PT_ERR_NOMEM || spp_pass == 1u) return rc;
-        spp_pass = (spp_pass + 1u) / 2u;
+        if (rc != PT_ERR_NOMEM || (spp_pass == 1u && slots <= 1u)) return rc == PT_ERR_NOMEM && ctx->error.empty() ? ptc_fail(ctx, rc, "pt_render_dev: render workspace does not fit") : rc;
+        if (spp_pass > 1u) spp_pass = (spp_pass + 1u) / 2u;
+        else slots -= 1u;
     }
     ctx->error.clear();
     int rc = PT_OK;
@@ -418,63 +457,87 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
     st.queue[0] = (uint32_t*)(base + o_q0); st.queue[1] = (uint32_t*)(base + o_q1); st.miss_queue = (uint32_t*)(base + o_qm);
     st.counts = (uint32_t*)(base + o_cnt); st.verts = (float4*)(base + o_verts);
     st.npix = npix;
+    st.cap = spp_pass * npix;
+    st.N = slots * st.cap;
 
     hipStream_t s = ctx->stream;
     PTC_HIP(ctx, hipEventRecord(ctx->ev[2], s));
     PTC_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * sizeof(float4), s));
+    PTC_HIP(ctx, hipMemsetAsync(st.counts, 0, 256, s));
     const uint32_t pix_blocks = (npix + PTC_BLOCK - 1) / PTC_BLOCK;
     size_t n_timed = 0;               // trace launches bracketed by ctx->trace_ev[2i], [2i+1]
 
     // The path loop runs AHEAD of the host: iteration i's kernels read the live count from the device,
-    // the count is copied back asynchronously and only consulted LOOKAHEAD iterations later to shrink
-    // the grids and to notice that every path has ended (at most LOOKAHEAD surplus iterations are
-    // enqueued; with a zero count their kernels return at once).
-    constexpr uint32_t LOOKAHEAD = 2, SLOTS = 8;
-    for (uint32_t done = 0; done < spp_count; done += spp_pass) {
-        const uint32_t this_spp = std::min(spp_pass, spp_count - done);
+    // the count is copied back asynchronously and only consulted LOOKAHEAD iterations later - to shrink
+    // the grids, to fold a pass whose paths have all ended, to admit the next pass once the paths in flight
+    // have thinned out, and to stop (at most LOOKAHEAD surplus iterations are enqueued at the end of the
+    // render; with a zero count their kernels return at once).
+    constexpr uint32_t LOOKAHEAD = 2, RING = 8;
+    struct Pass { uint32_t slot, spp, paths, born; };     // born: the first iteration that traces its paths
+    Pass fifo[PTC_MAX_SLOTS];                             // passes in flight, oldest first
+    uint32_t n_fifo = 0, next_slot = 0;
+    uint32_t generated = 0;                               // samples handed to k_generate so far
+    uint32_t enq = 0, harvested = 0;                      // iterations enqueued / counts read back
+    uint32_t watch_since = 0;                             // iterations >= this count the survivors of fifo[0]'s slot
+    uint32_t live_ub = 0;                                 // upper bound of the live count of the next iteration to enqueue
+    const uint32_t admit_below = (uint32_t)std::min<uint64_t>(st.cap, (uint64_t)((double)st.cap * ctx->tune_admit_frac));
+    auto admit = [&]() {                                  // the next pass joins the queue of iteration `enq`
+        const uint32_t this_spp = std::min(spp_pass, spp_count - generated);
         const uint32_t P = this_spp * npix;
-        const uint32_t sample_base = spp_begin + done;
-        st.P = P;
-        hipLaunchKernelGGL(k_generate, dim3((P + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, st, *cam, seed, sample_base);
+        st.sample_base[next_slot] = spp_begin + generated;
+        hipLaunchKernelGGL(k_generate, dim3((P + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, st, *cam, seed, next_slot, P, enq % 3u, enq & 1u);
+        hipLaunchKernelGGL(k_admit, dim3(1), dim3(64), 0, s, st.counts, enq % 3u, P, n_fifo == 0u ? 1u : 0u);
+        if (n_fifo == 0u) watch_since = enq;
+        fifo[n_fifo++] = Pass{next_slot, this_spp, P, enq};
+        next_slot = (next_slot + 1u) % slots;
+        generated += this_spp;
+        live_ub += P;
         ctx->stats.paths += P;
         ctx->stats.segments += P;
-        uint32_t live_ub = P;             // upper bound of the live count of the next iteration to enqueue
-        uint32_t enq = 0, harvested = 0;  // iterations enqueued / counts read back
-        bool finished = false;
-        while (!finished) {
-            if (enq < PTC_MAX_ITERS && enq - harvested <= LOOKAHEAD) {
-                rc = ptc_timed_event(ctx, 2 * n_timed);
-                if (rc != PT_OK) return rc;
-                rc = ptc_launch_trace(ctx, scene, (const pt_ray*)st.rays, nullptr, st.queue[enq & 1u], &st.counts[enq % 3u],
-                                      live_ub, (pt_hit*)st.hits);
-                if (rc != PT_OK) return rc;
-                rc = ptc_timed_event(ctx, 2 * n_timed + 1);
-                if (rc != PT_OK) return rc;
-                n_timed += 1;
-                const uint32_t shade_blocks = std::min<uint32_t>((live_ub + PTC_SHADE_SPAN - 1) / PTC_SHADE_SPAN, (uint32_t)ctx->n_cus * ctx->tune_shade_blocks_per_cu);
-                hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(PTC_BLOCK), 0, s, scene->view,
-                                   st, enq & 1u, enq % 3u, seed, sample_base);
-                PTC_HIP(ctx, hipMemcpyAsync(&ctx->h_counters[enq % SLOTS], &st.counts[(enq + 1u) % 3u], sizeof(uint32_t),
-                                            hipMemcpyDeviceToHost, s));
-                PTC_HIP(ctx, hipEventRecord(ctx->count_ev[enq % SLOTS], s));
-                enq += 1;
-                continue;
-            }
-            // read back the oldest outstanding count (blocks only when the host is LOOKAHEAD ahead)
-            PTC_HIP(ctx, hipEventSynchronize(ctx->count_ev[harvested % SLOTS]));
-            const uint32_t live = ctx->h_counters[harvested % SLOTS];
-            harvested += 1;
-            ctx->stats.segments += live;
-            live_ub = live;
-            if (live == 0u || harvested == PTC_MAX_ITERS) finished = true;
-        }
-        // counts of surplus iterations are zero; nothing to read.  The stream is in order, so the
-        // accumulate kernel sees every vertex column complete.
-        {
-            const uint32_t sky_blocks = std::min<uint32_t>((P + PTC_BLOCK - 1) / PTC_BLOCK, (uint32_t)ctx->n_cus * 16u);
+    };
+    auto fold_front = [&](bool& sky_done) {               // every path of the oldest pass has ended
+        if (!sky_done) {
+            const uint32_t sky_blocks = std::min<uint32_t>((st.N + PTC_BLOCK - 1) / PTC_BLOCK, (uint32_t)ctx->n_cus * 16u);
             hipLaunchKernelGGL(k_sky, dim3(sky_blocks), dim3(PTC_BLOCK), 0, s, scene->view, scene->d_sky, st, normalize_sky);
+            sky_done = true;
         }
-        hipLaunchKernelGGL(k_accumulate, dim3(pix_blocks), dim3(PTC_BLOCK), 0, s, st, this_spp, acc);
+        hipLaunchKernelGGL(k_accumulate, dim3(pix_blocks), dim3(PTC_BLOCK), 0, s, st, fifo[0].slot, fifo[0].spp, acc);
+        for (uint32_t i = 1; i < n_fifo; ++i) fifo[i - 1] = fifo[i];
+        n_fifo -= 1u;
+        watch_since = enq;                                // k_shade launches from now on watch the new front
+    };
+    if (spp_count != 0u) admit();
+    while (n_fifo != 0u) {
+        if (enq - harvested <= LOOKAHEAD) {
+            rc = ptc_timed_event(ctx, 2 * n_timed);
+            if (rc != PT_OK) return rc;
+            rc = ptc_launch_trace(ctx, scene, (const pt_ray*)st.rays, nullptr, st.queue[enq & 1u], &st.counts[2u * (enq % 3u)],
+                                  live_ub, (pt_hit*)st.hits);
+            if (rc != PT_OK) return rc;
+            rc = ptc_timed_event(ctx, 2 * n_timed + 1);
+            if (rc != PT_OK) return rc;
+            n_timed += 1;
+            const uint32_t shade_blocks = std::max(1u, std::min<uint32_t>((live_ub + PTC_SHADE_SPAN - 1) / PTC_SHADE_SPAN, (uint32_t)ctx->n_cus * ctx->tune_shade_blocks_per_cu));
+            hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(PTC_BLOCK), 0, s, scene->view,
+                               st, enq & 1u, enq % 3u, seed, fifo[0].slot);
+            PTC_HIP(ctx, hipMemcpyAsync(&ctx->h_counters[2u * (enq % RING)], &st.counts[2u * ((enq + 1u) % 3u)], 2 * sizeof(uint32_t),
+                                        hipMemcpyDeviceToHost, s));
+            PTC_HIP(ctx, hipEventRecord(ctx->count_ev[enq % RING], s));
+            enq += 1;
+            continue;
+        }
+        // read back the oldest outstanding pair (blocks only when the host is LOOKAHEAD ahead): what iteration h + 1 finds
+        // in its queue, before any pass admitted at h + 1 or later
+        const uint32_t h = harvested;
+        PTC_HIP(ctx, hipEventSynchronize(ctx->count_ev[h % RING]));
+        const uint32_t live = ctx->h_counters[2u * (h % RING)], live_watched = ctx->h_counters[2u * (h % RING) + 1u];
+        harvested += 1;
+        ctx->stats.segments += live;
+        live_ub = live;
+        for (uint32_t i = 0; i < n_fifo; ++i) if (fifo[i].born > h) live_ub += fifo[i].paths;      // admitted since
+        bool sky_done = false;
+        while (n_fifo != 0u && fifo[0].born <= h && (live == 0u || (h >= watch_since && live_watched == 0u))) fold_front(sky_done);
+        if (generated < spp_count && n_fifo < slots && live_ub <= admit_below) admit();
     }
     const float inv_total = (mode == PT_RENDER_FINAL) ? 1.0f / (float)spp_total : 0.0f;
     hipLaunchKernelGGL(k_output, dim3(pix_blocks), dim3(PTC_BLOCK), 0, s, acc, (float4*)d_xyzw, npix, mode, inv_total,

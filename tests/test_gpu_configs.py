@@ -57,18 +57,30 @@ def test_config3_full_frame_sample_and_64spp_image(gpu_ctx, soup1m_hw, golden):
     assert st.paths == 240 * 135 * 64 and st.segments > 3 * st.paths
 
 
-def test_config3_image_is_the_same_when_cut_into_many_passes(monkeypatch, golden):
-    """PTC_PASS_PATHS = 65 536 paths in flight: the 64 spp of the 240x135 frame become 32 passes of 2 spp; each pixel's samples
-    are still added in sample order, so the image is the one-pass image bit for bit."""
+@pytest.mark.parametrize("slots,admit", [(1, 25), (2, 25), (3, 25), (4, 100), (3, 0)])
+def test_config3_image_is_the_same_when_cut_into_many_passes(monkeypatch, golden, slots, admit):
+    """PTC_PASS_PATHS = 129 600 paths in flight: the 64 spp of the 240x135 frame become passes of 4 / slots samples, up to
+    `slots` of them in flight together (a pass joins the queue once <= admit % of a pass's paths are live; it is folded into
+    the image when its last path has ended, oldest pass first).  Each pixel's samples are still added in sample order, so the
+    image is the one-pass image bit for bit, whatever the schedule."""
     meta, npz = golden
-    monkeypatch.setenv("PTC_PASS_PATHS", "65536")
+    monkeypatch.setenv("PTC_PASS_PATHS", str(4 * 240 * 135))
+    monkeypatch.setenv("PTC_PASS_SLOTS", str(slots))
+    monkeypatch.setenv("PTC_ADMIT_PERCENT", str(admit))
     ctx = core.Context(0)
     try:
         arr = workloads.soup_scene(1_000_000, sky=workloads.hw_sky())
         sc = ctx.scene(arr)
         got = ctx.render(sc, 240, 135, 0, 64, 64, seed=1)
         assert same_image(got, npz["config3_240x135_64spp"])
-        assert ctx.stats().trace_launches > 32 * 8          # 32 passes, each with its own bounce iterations
+        st = ctx.stats()
+        assert st.paths == 240 * 135 * 64
+        per_pass = st.trace_launches / (64 // max(1, 4 // slots))
+        print(f"slots {slots} admit {admit}: {st.trace_launches} launches, {per_pass:.1f} per pass")
+        if slots == 1 or admit == 0:
+            assert per_pass > 12            # one pass at a time: every pass runs its own tail of thin iterations
+        else:                               # passes overlap: the tail of one rides in the launches of the next
+            assert per_pass < 24 / slots + 1.5
         sc.close()
     finally:
         ctx.close()
