@@ -110,6 +110,7 @@ static int pt_init_body(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_wide_collapse = std::min(2u, env_u32("PTC_WIDE_COLLAPSE", ctx->tune_wide_collapse));
     ctx->tune_shade_blocks_per_cu = std::max(1u, env_u32("PTC_SHADE_BLOCKS_PER_CU", ctx->tune_shade_blocks_per_cu));
     ctx->tune_ring = env_u32("PTC_RING", ctx->tune_ring);
+    ctx->tune_flatten = std::min(2u, env_u32("PTC_FLATTEN", ctx->tune_flatten));
     ctx->tune_host_chunk = std::max(1u << 12, std::min(1u << 28, env_u32("PTC_HOST_CHUNK", ctx->tune_host_chunk)));
     ctx->tune_pass_paths = std::max(1u << 16, std::min(192u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
     ctx->tune_pass_slots = std::max(1u, std::min(4u, env_u32("PTC_PASS_SLOTS", ctx->tune_pass_slots)));
@@ -164,8 +165,28 @@ extern "C" int pt_scene_get_info(const pt_scene* scene, pt_scene_info* out) {
 
 namespace {
 
+// A host array whose pages are first touched by whoever fills it: a std::vector of 2.9 GB (20 M triangles) spends 0.5 s
+// zeroing itself on one core before the worker threads overwrite every byte.
 template <class T>
-int upload(pt_ctx* ctx, pt_scene* sc, const std::vector<T>& host, const T** dev, const char* what) {
+struct RawBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    explicit RawBuf(size_t count) : n(count) {
+        if (n) { p = static_cast<T*>(std::malloc(n * sizeof(T))); if (!p) throw std::bad_alloc(); }
+    }
+    ~RawBuf() { std::free(p); }
+    RawBuf(const RawBuf&) = delete;
+    RawBuf& operator=(const RawBuf&) = delete;
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
+template <class C, class T>
+int upload(pt_ctx* ctx, pt_scene* sc, const C& host, const T** dev, const char* what) {
     *dev = nullptr;
     size_t bytes = host.size() * sizeof(T);
     if (bytes == 0) bytes = sizeof(T);          // keep pointers valid for empty arrays
@@ -234,10 +255,14 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
 
     // ---- validate + flatten the node vector ------------------------------------------------------
     // Every child index must point FORWARD (preorder) so that traversal terminates and never
-    // leaves the array; every triangle must be referenced by exactly one leaf.
+    // leaves the array; every triangle must be referenced by exactly one leaf.  Done on the device after the uploads
+    // (lbvh.hip: ptc_flatten_nodes) unless PTC_FLATTEN or PTC_WIDE_COLLAPSE ask for this host-side loop (1), or for both
+    // and a byte-for-byte comparison (2).
     const uint32_t n_nodes = d->n_nodes;
-    std::vector<uint32_t> internal_rank(n_nodes, 0u);
+    const bool host_flatten = !lbvh && (ctx->tune_flatten != 0u || ctx->tune_wide_collapse != 0u);
+    std::vector<uint32_t> internal_rank(host_flatten ? n_nodes : 0u, 0u);
     uint32_t n_internal = 0;
+    if (host_flatten) {
     for (uint32_t i = 0; i < n_nodes; ++i) {
         const pt_bvh_node& nd = d->nodes[i];
         if (nd.is_leaf) {
@@ -248,13 +273,13 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
             internal_rank[i] = n_internal++;
         }
     }
-    if (!lbvh && N && n_internal != N - 1) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: expected n_triangles-1 internal nodes");
-
+    if (N && n_internal != N - 1) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: expected n_triangles-1 internal nodes");
+    }
     std::vector<float4> nodes((size_t)n_internal * 4u);
     std::vector<uint32_t> rank_depth(n_internal, 0u);       // depth of internal node by rank (root = 1)
     uint32_t max_depth = 0;
     bool boxes_ordered = true;
-    {
+    if (host_flatten) {
         // depth = internal nodes on the longest root-to-leaf path (bounds the traversal stack)
         std::vector<uint32_t> depth(n_nodes, 0u);
         if (n_nodes) depth[0] = d->nodes[0].is_leaf ? 0u : 1u;
@@ -288,7 +313,7 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
             q[3] = make_float4(nd.child_r_aabb.max[0], nd.child_r_aabb.max[1], nd.child_r_aabb.max[2], 0.0f);
         }
     }
-    if (max_depth > 4096) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_scene_create: BVH deeper than 4096 levels");
+    if (max_depth > PTC_MAX_BVH_DEPTH) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_scene_create: BVH deeper than 4096 levels");
 
     // ---- wide nodes: collapse two binary levels into one record (device_types.h) -----------------------
     // Done on the device after the upload (lbvh.hip: depths, prefix sum, k_wide) unless PTC_WIDE_COLLAPSE says otherwise:
@@ -336,7 +361,7 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
     }
 
     // ---- Triangle::new (triangle.rs:50-60) ---------------------------------------------------------
-    std::vector<float4> tris((size_t)N * 3u), shade((size_t)N * 5u), surf(N), boxes(lbvh ? (size_t)N * 2u : 0u);
+    RawBuf<float4> tris((size_t)N * 3u), shade((size_t)N * 5u), surf(N), boxes(lbvh ? (size_t)N * 2u : 0u);   // every entry is written below
     std::atomic<bool> bad_material{false};
     auto precompute = [&](uint32_t begin, uint32_t end) {
     for (uint32_t i = begin; i < end; ++i) {
@@ -469,12 +494,33 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
         return rc;
     }
     ctx->stats = pt_stats{};
+    if (!lbvh && (!host_flatten || ctx->tune_flatten == 2u)) {
+        float4* d_nodes = nullptr;
+        uint32_t dev_internal = 0;
+        bool dev_ordered = true;
+        rc = ptc_flatten_nodes(ctx, d->nodes, n_nodes, N, &d_nodes, &dev_internal, &dev_ordered);
+        if (rc != PT_OK) { pt_scene_destroy(ctx, sc.release()); return rc; }
+        if (d_nodes) s->allocations.push_back(d_nodes);
+        if (host_flatten) {                              // PTC_FLATTEN=2: the two must agree on every byte
+            std::vector<float4> back((size_t)dev_internal * 4u);
+            const bool same = dev_internal == n_internal && dev_ordered == boxes_ordered &&
+                              (back.empty() || (hipMemcpy(back.data(), d_nodes, back.size() * sizeof(float4), hipMemcpyDeviceToHost) == hipSuccess &&
+                                                std::memcmp(back.data(), nodes.data(), back.size() * sizeof(float4)) == 0));
+            if (!same) { pt_scene_destroy(ctx, sc.release()); return ptc_fail(ctx, PT_ERR_HIP, "pt_scene_create: device-side node flattening disagrees with the host's"); }
+        } else {
+            s->view.nodes = d_nodes;
+            s->info.device_bytes += (size_t)dev_internal * 64u;
+            n_internal = dev_internal;
+            boxes_ordered = dev_ordered;
+        }
+    }
     if (!lbvh && n_internal && wide_mode != 1u) {
         float4* d_wide = nullptr;
         uint32_t n_wide = 0, dev_depth = 0, dev_wide_depth = 0;
         rc = ptc_build_wide_from_nodes(ctx, s->view.nodes, n_internal, &d_wide, &n_wide, &dev_depth, &dev_wide_depth);
         if (rc != PT_OK) { pt_scene_destroy(ctx, sc.release()); return rc; }
         s->allocations.push_back(d_wide);
+        if (!host_flatten) max_depth = dev_depth;
         bool same = dev_depth == max_depth;
         if (wide_mode == 2u) {
             std::vector<float4> back((size_t)n_wide * 8u);

@@ -112,6 +112,7 @@ struct pt_ctx {
     uint32_t tune_blocks_per_cu = 6;
     uint32_t tune_refill = 16;
     uint32_t tune_wide_collapse = 0;     // wide records of caller-supplied trees: 0 on the device, 1 on the host, 2 both + compare
+    uint32_t tune_flatten = 0;           // caller-supplied node vectors are validated and flattened: 0 on the device, 1 on the host, 2 both + compare
     uint32_t tune_ticket = 64;           // rays a wave reserves per ticket atomic (after its static first block of 64)
     uint32_t tune_shade_blocks_per_cu = 64; // k_shade grid cap (blocks loop over the queue beyond it)
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the EXACT traversal kernel (8, 12 or 16)
@@ -168,6 +169,11 @@ int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, c
 // lbvh.hip: device-side build into the layouts above (boxes: {min,0},{max,0} per triangle, host memory)
 int ptc_build_lbvh(pt_ctx* ctx, const float4* h_boxes, uint32_t n, float4** d_nodes, float4** d_wide, uint32_t* n_wide,
                    uint32_t* max_depth, uint32_t* wide_depth, float* build_ms);
+
+// lbvh.hip: pt_scene_create's node vector validated and flattened on the device (the host-side loop stays behind PTC_FLATTEN=1)
+int ptc_flatten_nodes(pt_ctx* ctx, const pt_bvh_node* h_nodes, uint32_t n_nodes, uint32_t n_tris, float4** d_nodes,
+                      uint32_t* n_internal, bool* boxes_ordered);
+#define PTC_MAX_BVH_DEPTH 4096u
 
 // the wide records of a binary node array already in HBM (same numbering and child order as the host-side collapse)
 int ptc_build_wide_from_nodes(pt_ctx* ctx, const float4* d_nodes, uint32_t n_internal, float4** d_wide, uint32_t* n_wide,

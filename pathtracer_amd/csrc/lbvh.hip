@@ -179,8 +179,8 @@ __global__ __launch_bounds__(LB_BLOCK) void k_depth(const uint32_t* __restrict__
                                                     uint32_t* __restrict__ is_wide, uint32_t* __restrict__ stats) {
     const uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x;
     if (i >= n_internal) return;
-    uint32_t d = 1u;
-    for (uint32_t c = parent_of_internal[i]; c != 0xFFFFFFFFu; c = parent_of_internal[c]) ++d;
+    uint32_t d = 1u;            // (the walk gives up past PTC_MAX_BVH_DEPTH: the caller rejects such a tree)
+    for (uint32_t c = parent_of_internal[i]; c != 0xFFFFFFFFu && d <= PTC_MAX_BVH_DEPTH; c = parent_of_internal[c]) ++d;
     is_wide[i] = d & 1u;
     atomicMax(&stats[0], d);
 }
@@ -228,6 +228,54 @@ __global__ __launch_bounds__(LB_BLOCK) void k_parents(const float4* __restrict__
     if (!(l & PTC_LEAF_BIT)) parent_of_internal[l] = i;
     if (!(r & PTC_LEAF_BIT)) parent_of_internal[r] = i;
     if (i == 0u) parent_of_internal[0] = 0xFFFFFFFFu;
+}
+
+// ---- caller-supplied node vectors (pt_scene_create): validate and flatten on the device -------------------------------
+// err bits: 1 leaf shape_index out of range, 2 child index not a forward preorder index, 4 node referenced by two parents
+// (so another is unreachable), 8 triangle referenced by two leaves, 16 (not an error) a child box with min > max
+__global__ __launch_bounds__(LB_BLOCK) void k_node_flags(const uint4* __restrict__ raw, uint32_t n_nodes, uint32_t n_tris,
+                                                         uint32_t* __restrict__ is_internal, uint32_t* __restrict__ err) {
+    const uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint4 h = raw[4u * (size_t)i];            // {is_leaf, shape_index, child_l_index, child_r_index}
+    uint32_t bad = 0u;
+    if (h.x) { if (h.y >= n_tris) bad = 1u; }
+    else if (h.z <= i || h.z >= n_nodes || h.w <= i || h.w >= n_nodes) bad = 2u;
+    is_internal[i] = h.x ? 0u : 1u;
+    if (bad) atomicOr(err, bad);
+}
+
+// one {child boxes, child refs} record per internal node, numbered by rank among internal nodes (device_types.h); every
+// child marks its bit: with forward indices, 2N - 2 references and no bit marked twice, every node but the root has exactly
+// one parent and every triangle exactly one leaf
+__global__ __launch_bounds__(LB_BLOCK) void k_node_pack(const uint4* __restrict__ raw, uint32_t n_nodes, const uint32_t* __restrict__ is_internal,
+                                                        const uint32_t* __restrict__ rank, uint32_t* __restrict__ node_bits,
+                                                        uint32_t* __restrict__ tri_bits, float4* __restrict__ nodes, uint32_t* __restrict__ err) {
+    const uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (i >= n_nodes || !is_internal[i]) return;
+    const uint4 h = raw[4u * (size_t)i], b0 = raw[4u * (size_t)i + 1u], b1 = raw[4u * (size_t)i + 2u], b2 = raw[4u * (size_t)i + 3u];
+    uint32_t bad = 0u, refs[2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t c = side ? h.w : h.z;
+        const uint4 ch = raw[4u * (size_t)c];
+        if (atomicOr(&node_bits[c >> 5], 1u << (c & 31u)) & (1u << (c & 31u))) bad |= 4u;
+        if (ch.x) {
+            refs[side] = PTC_LEAF_BIT | ch.y;
+            if (atomicOr(&tri_bits[ch.y >> 5], 1u << (ch.y & 31u)) & (1u << (ch.y & 31u))) bad |= 8u;
+        } else refs[side] = rank[c];
+    }
+    // child_l_aabb = {b0.x b0.y b0.z | b0.w b1.x b1.y}, child_r_aabb = {b1.z b1.w b2.x | b2.y b2.z b2.w}
+    const float lmin[3] = {__uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z)}, lmax[3] = {__uint_as_float(b0.w), __uint_as_float(b1.x), __uint_as_float(b1.y)};
+    const float rmin[3] = {__uint_as_float(b1.z), __uint_as_float(b1.w), __uint_as_float(b2.x)}, rmax[3] = {__uint_as_float(b2.y), __uint_as_float(b2.z), __uint_as_float(b2.w)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (lmin[k] > lmax[k] || rmin[k] > rmax[k]) bad |= 16u;
+    float4* q = &nodes[4u * (size_t)rank[i]];
+    q[0] = make_float4(lmin[0], lmin[1], lmin[2], __uint_as_float(refs[0]));
+    q[1] = make_float4(lmax[0], lmax[1], lmax[2], __uint_as_float(refs[1]));
+    q[2] = make_float4(rmin[0], rmin[1], rmin[2], 0.0f);
+    q[3] = make_float4(rmax[0], rmax[1], rmax[2], 0.0f);
+    if (bad) atomicOr(err, bad);
 }
 
 struct Scratch {                     // frees what it holds when the build leaves, however it leaves
@@ -363,6 +411,7 @@ int ptc_build_wide_from_nodes(pt_ctx* ctx, const float4* d_nodes, uint32_t n_int
     PTC_HIP(ctx, hipMemcpyAsync(h_stats, stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
     PTC_HIP(ctx, hipStreamSynchronize(s));
     const uint32_t nw = h_last[0] + h_last[1];
+    if (h_stats[0] > PTC_MAX_BVH_DEPTH) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_scene_create: BVH deeper than 4096 levels");
     if (nw == 0 || h_stats[0] == 0) return ptc_fail(ctx, PT_ERR_HIP, "wide collapse produced no nodes");
     float4* wide = nullptr;
     PTC_HIP(ctx, hipMalloc((void**)&wide, (size_t)nw * 8u * sizeof(float4)));
@@ -374,5 +423,64 @@ int ptc_build_wide_from_nodes(pt_ctx* ctx, const float4* d_nodes, uint32_t n_int
     *n_wide = nw;
     *max_depth = h_stats[0];
     *wide_depth = (h_stats[0] + 1u) / 2u;
+    return PT_OK;
+}
+
+
+// pt_scene_create's node vector, validated and flattened on the device: the raw 64-byte entries are uploaded as they are,
+// the internal nodes are ranked by a prefix sum and packed into the binary node array of device_types.h.  Same verdicts as
+// the host-side loop in core.hip (PTC_FLATTEN=1): every child index points forward, every node but the root has one
+// parent, every triangle one leaf.  *d_nodes (n_internal x 4 float4) is the caller's on success.
+int ptc_flatten_nodes(pt_ctx* ctx, const pt_bvh_node* h_nodes, uint32_t n_nodes, uint32_t n_tris, float4** d_nodes,
+                      uint32_t* n_internal, bool* boxes_ordered) {
+    static_assert(sizeof(pt_bvh_node) == 64, "k_node_flags / k_node_pack read a node as four 16-byte words");
+    *d_nodes = nullptr; *n_internal = 0; *boxes_ordered = true;
+    if (n_nodes == 0) return PT_OK;
+    hipStream_t s = ctx->stream;
+    Scratch tmp;
+    uint4* raw = nullptr;
+    uint32_t *is_internal = nullptr, *rank = nullptr, *node_bits = nullptr, *tri_bits = nullptr, *err = nullptr;
+    int rc;
+    const size_t nb_words = ((size_t)n_nodes + 31u) / 32u, tb_words = ((size_t)n_tris + 31u) / 32u;
+    if ((rc = tmp.get(ctx, &raw, 4 * (size_t)n_nodes, "raw nodes")) || (rc = tmp.get(ctx, &is_internal, n_nodes, "node flags")) ||
+        (rc = tmp.get(ctx, &rank, n_nodes, "node ranks")) || (rc = tmp.get(ctx, &node_bits, nb_words, "node marks")) ||
+        (rc = tmp.get(ctx, &tri_bits, tb_words, "triangle marks")) || (rc = tmp.get(ctx, &err, 4, "node verdict")))
+        return rc;
+    PTC_HIP(ctx, hipMemcpyAsync(raw, h_nodes, (size_t)n_nodes * sizeof(pt_bvh_node), hipMemcpyHostToDevice, s));
+    PTC_HIP(ctx, hipMemsetAsync(err, 0, 4 * sizeof(uint32_t), s));
+    PTC_HIP(ctx, hipMemsetAsync(node_bits, 0, nb_words * sizeof(uint32_t), s));
+    PTC_HIP(ctx, hipMemsetAsync(tri_bits, 0, std::max<size_t>(tb_words, 1) * sizeof(uint32_t), s));
+    const uint32_t gn = (n_nodes + LB_BLOCK - 1) / LB_BLOCK;
+    hipLaunchKernelGGL(k_node_flags, dim3(gn), dim3(LB_BLOCK), 0, s, raw, n_nodes, n_tris, is_internal, err);
+    size_t scan_bytes = 0;
+    PTC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_internal, rank, (int)n_nodes, s));
+    char* scan_tmp = nullptr;
+    if ((rc = tmp.get(ctx, &scan_tmp, scan_bytes, "node scan workspace"))) return rc;
+    PTC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, is_internal, rank, (int)n_nodes, s));
+    uint32_t h_last[2] = {0, 0}, h_err = 0;
+    PTC_HIP(ctx, hipMemcpyAsync(&h_last[0], rank + (n_nodes - 1u), 4, hipMemcpyDeviceToHost, s));
+    PTC_HIP(ctx, hipMemcpyAsync(&h_last[1], is_internal + (n_nodes - 1u), 4, hipMemcpyDeviceToHost, s));
+    PTC_HIP(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));
+    PTC_HIP(ctx, hipStreamSynchronize(s));
+    if (h_err & 1u) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: leaf shape_index out of range");
+    if (h_err & 2u) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: child index is not a forward preorder index");
+    const uint32_t ni = h_last[0] + h_last[1];
+    if (n_tris && ni != n_tris - 1u) return ptc_fail(ctx, PT_ERR_INVALID, "pt_scene_create: expected n_triangles-1 internal nodes");
+    *n_internal = ni;
+    if (ni == 0) return PT_OK;                          // a single leaf
+    float4* nodes = nullptr;
+    PTC_HIP(ctx, hipMalloc((void**)&nodes, (size_t)ni * 4u * sizeof(float4)));
+    hipLaunchKernelGGL(k_node_pack, dim3(gn), dim3(LB_BLOCK), 0, s, raw, n_nodes, is_internal, rank, node_bits, tri_bits, nodes, err);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(nodes); return ptc_hip(ctx, e, "node flattening"); }
+    if (h_err & 12u) {
+        (void)hipFree(nodes);
+        return ptc_fail(ctx, PT_ERR_INVALID, (h_err & 4u) ? "pt_scene_create: node referenced by two parents (another is unreachable from the root)"
+                                                         : "pt_scene_create: triangle referenced by two leaves");
+    }
+    *boxes_ordered = (h_err & 16u) == 0u;
+    *d_nodes = nodes;
     return PT_OK;
 }

@@ -255,6 +255,73 @@ def test_device_wide_collapse_is_byte_identical_to_the_host_loop(monkeypatch):
         ctx.close()
 
 
+def chain_scene(n):
+    """n triangles hung on a right-leaning chain: node 2k = Node{left: leaf 2k+1, right: 2k+2}; depth n - 1."""
+    tris = workloads.soup_scene(n).triangles
+    nodes = np.zeros(2 * n - 1, dtype=abi.BVH_NODE)
+    lo = np.minimum(np.minimum(tris["a"], tris["b"]), tris["c"])
+    hi = np.maximum(np.maximum(tris["a"], tris["b"]), tris["c"])
+    suf_lo = np.minimum.accumulate(lo[::-1], axis=0)[::-1]          # box of triangles k..n-1
+    suf_hi = np.maximum.accumulate(hi[::-1], axis=0)[::-1]
+    for k in range(n - 1):
+        nd = nodes[2 * k]
+        nd["child_l_index"], nd["child_r_index"] = 2 * k + 1, 2 * k + 2
+        nd["child_l_aabb"]["min"], nd["child_l_aabb"]["max"] = lo[k], hi[k]
+        nd["child_r_aabb"]["min"], nd["child_r_aabb"]["max"] = suf_lo[k + 1], suf_hi[k + 1]
+        nodes[2 * k + 1]["is_leaf"], nodes[2 * k + 1]["shape_index"] = 1, k
+    nodes[2 * n - 2]["is_leaf"], nodes[2 * n - 2]["shape_index"] = 1, n - 1
+    return abi.SceneArrays(tris, nodes, workloads.soup_scene(8).materials, core.sky_d65(1.0))
+
+
+@pytest.mark.parametrize("flatten", [0, 1, 2])
+def test_caller_nodes_are_validated_and_flattened_alike_on_device_and_host(monkeypatch, oracle, flatten):
+    """PTC_FLATTEN: 0 = the kernels of lbvh.hip (default), 1 = the host loop of core.hip, 2 = both, and scene creation fails
+    unless the two node arrays are byte-identical.  The verdicts on bad node vectors are the same either way."""
+    monkeypatch.setenv("PTC_FLATTEN", str(flatten))
+    ctx = core.Context(0)
+    try:
+        for n in (1, 2, 3, 5, 8, 33, 1000, 20_000, 300_000):
+            arr = workloads.soup_scene(n)
+            sc = ctx.scene(arr)
+            assert sc.info().n_internal_nodes == n - 1
+            if n == 20_000:
+                rays = core.gen_primary_rays(96, 54)
+                assert ctx.trace(sc, rays).tobytes() == oracle.trace(oracle.scene(arr), rays).tobytes()
+                assert np.array_equal(sc.bvh(), arr.nodes)
+            sc.close()
+        ctx.scene(workloads.box_scene()).close()
+        deep = chain_scene(600)                                   # depth 599: deep but legal
+        sc = ctx.scene(deep)
+        rays = core.gen_primary_rays(64, 36)
+        assert sc.info().max_depth == 599 and ctx.trace(sc, rays).tobytes() == oracle.trace(oracle.scene(deep), rays).tobytes()
+        sc.close()
+        with pytest.raises(core.PtError) as e:                    # deeper than the traversal stacks are sized for
+            ctx.scene(chain_scene(4200))
+        assert e.value.code == abi.PT_ERR_UNSUPPORTED and "4096" in str(e.value)
+
+        arr = workloads.soup_scene(500)
+
+        def verdict(mutate):
+            a = abi.SceneArrays(arr.triangles.copy(), arr.nodes.copy(), arr.materials.copy(), arr.sky)
+            mutate(a.nodes)
+            with pytest.raises(core.PtError) as e:
+                ctx.scene(a)
+            assert e.value.code == abi.PT_ERR_INVALID and "pt_scene_create" in str(e.value)
+            return str(e.value)
+        leaves, inner = np.flatnonzero(arr.nodes["is_leaf"]), np.flatnonzero(arr.nodes["is_leaf"] == 0)
+        assert "shape_index" in verdict(lambda nd: nd["shape_index"].__setitem__(leaves[7], 500))
+        assert "forward" in verdict(lambda nd: nd["child_l_index"].__setitem__(inner[5], inner[5]))          # a node that is its own child
+        assert "forward" in verdict(lambda nd: nd["child_r_index"].__setitem__(inner[9], 999))               # past the end
+        assert "forward" in verdict(lambda nd: nd["child_r_index"].__setitem__(inner[40], 0))                # back to the root
+        assert "two leaves" in verdict(lambda nd: nd["shape_index"].__setitem__(leaves[3], nd["shape_index"][leaves[4]]))
+        # two parents for one node: its sibling subtree is unreachable
+        msg = verdict(lambda nd: nd["child_l_index"].__setitem__(inner[2], nd["child_r_index"][inner[2]]))
+        assert "unreachable" in msg or "two leaves" in msg
+        assert "internal nodes" in verdict(lambda nd: nd["is_leaf"].__setitem__(inner[-1], 1))                # a Node turned Leaf
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("n_tris", [0, 1, 2, 7, 20_000])
 def test_scene_bvh_round_trip_of_caller_nodes(gpu_ctx, n_tris):
     """pt_scene_get_bvh undoes the flattening of pt_scene_create: the caller's `BVH.nodes` come back (Node fields of leaf
