@@ -79,12 +79,13 @@ PT_HD uint32_t pt_rng_u32(pt_rng* r) {
     }
     uint32_t w = r->index & 3u;
     r->index += 1u;
-    /* select without dynamic register indexing */
-    uint32_t x = r->block.v[0];
-    x = (w == 1u) ? r->block.v[1] : x;
-    x = (w == 2u) ? r->block.v[2] : x;
-    x = (w == 3u) ? r->block.v[3] : x;
-    return x;
+    /* Word w of the block by masks: no dynamic register index, and nothing the compiler can turn into a load from a
+     * selected ADDRESS (it did that to a chain of `w == k ? v[k] : x`, which put the whole generator into scratch
+     * memory: 44 bytes stored per lane and draw loop, each of them a write that reached HBM). */
+    const uint32_t b0 = r->block.v[0], b1 = r->block.v[1], b2 = r->block.v[2], b3 = r->block.v[3];
+    const uint32_t lo = b0 ^ ((b0 ^ b1) & (0u - (w & 1u)));       /* w odd: b1, else b0 */
+    const uint32_t hi = b2 ^ ((b2 ^ b3) & (0u - (w & 1u)));       /* w odd: b3, else b2 */
+    return lo ^ ((lo ^ hi) & (0u - (w >> 1)));
 }
 
 /* rand 0.8.5 `Standard` for f32: 24 random bits, [0, 1). */

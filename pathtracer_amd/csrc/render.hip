@@ -537,6 +537,10 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
         for (uint32_t i = 0; i < n_fifo; ++i) if (fifo[i].born > h) live_ub += fifo[i].paths;      // admitted since
         bool sky_done = false;
         while (n_fifo != 0u && fifo[0].born <= h && (live == 0u || (h >= watch_since && live_watched == 0u))) fold_front(sky_done);
+        // a path takes part in at most PTC_MAX_ITERS iterations (k_shade counts them in its state word): a pass that outlives
+        // that has lost its state to something else writing the workspace - stop instead of enqueueing for ever
+        if (n_fifo != 0u && h > fifo[0].born + PTC_MAX_ITERS + 8u)
+            return ptc_fail(ctx, PT_ERR_HIP, "pt_render_dev: paths outlived the iteration limit (workspace corrupted?)");
         if (generated < spp_count && n_fifo < slots && live_ub <= admit_below) admit();
     }
     const float inv_total = (mode == PT_RENDER_FINAL) ? 1.0f / (float)spp_total : 0.0f;

@@ -19,4 +19,4 @@ for k in sorted(acc):
     print(k)
     for c in sorted(acc[k]):
         v = acc[k][c]
-        print(f"    {c:34s} n={len(v):4d} mean={sum(v)/len(v):.6g}")
+        print(f"    {c:34s} n={len(v):4d} mean={sum(v)/len(v):.6g} sum={sum(v):.6g}")
