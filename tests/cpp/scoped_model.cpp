@@ -87,8 +87,10 @@ extern "C" {
 //            sign-select form decides differently from the general form (must stay 0),
 //        [1] deepest stack, [2] wide records visited, [3] triangle tests, [4] RESTORE entries pushed,
 //        [5] entries pushed (RESTOREs included), [6] popped entries that were entered, [7] loop trips (record + leaf + pops of one lane)
-int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triangle* tris, uint32_t n_tris,
-                     const pt_ray* rays, const uint32_t* start, uint64_t n, pt_hit* out, uint8_t* flagged, uint64_t stats[8]) {
+// per_ray_trips (may be NULL): loop trips of each ray - the length of its dependent chain of record / triangle fetches
+int ptm_trace_scoped_trips(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triangle* tris, uint32_t n_tris,
+                           const pt_ray* rays, const uint32_t* start, uint64_t n, pt_hit* out, uint8_t* flagged, uint64_t stats[8],
+                           uint32_t* per_ray_trips) {
     std::vector<F4> rec((size_t)n_tris * 3);
     for (uint32_t i = 0; i < n_tris; ++i) precompute(tris[i], &rec[(size_t)i * 3]);
     std::vector<Wide> wide(n_nodes);
@@ -116,6 +118,7 @@ int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triang
             if (st.size() > stats[1]) stats[1] = st.size();
         };
         bool alive = true;
+        const uint64_t trips_before = stats[7];
         while (alive) {
             stats[7] += 1;
             if (!(cur & PTC_LEAF_BIT)) {
@@ -175,8 +178,14 @@ int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triang
             }
         }
         if (!flagged[i]) out[i] = pt_hit{best_id, best_id == PT_NO_TRIANGLE ? 0.0f : best_t, best_u, best_v};
+        if (per_ray_trips) per_ray_trips[i] = (uint32_t)(stats[7] - trips_before);
     }
     return 0;
+}
+
+int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triangle* tris, uint32_t n_tris,
+                     const pt_ray* rays, const uint32_t* start, uint64_t n, pt_hit* out, uint8_t* flagged, uint64_t stats[8]) {
+    return ptm_trace_scoped_trips(nodes, n_nodes, tris, n_tris, rays, start, n, out, flagged, stats, nullptr);
 }
 
 }  // extern "C"
