@@ -272,14 +272,25 @@ def main():
                 per_path = (segs * (32 + 16 + 2 * 128 + 64 + 48) + 64 * nodes + 48 * tris_t) / paths + 16
                 total = per_path * a.width * a.height * a.spectral_spp
                 gbps = total / spectral["seconds"] / 1e9
+                # counter bytes of the integrator's kernels (tools/pmc_integrator.sh on this scene and frame), per path-sample
+                it, itp = {}, os.path.join(ROOT, "profiles", "integrator_traffic.json")
+                if os.path.exists(itp):
+                    it = json.load(open(itp))
+                    if not (it.get("tris") == a.tris and it.get("width") == a.width and it.get("height") == a.height and it.get("traversal") == a.traversal):
+                        it = {}
+                traffic = it["bytes_per_path_sample"] * a.width * a.height * a.spectral_spp if it else None
                 spectral["roofline"] = {
-                    "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": None,
+                    "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": traffic,
+                    "hbm_counter_frac": (traffic / spectral["seconds"] / 8e12) if traffic else None,
+                    "traffic_bytes_per_path_sample": it.get("bytes_per_path_sample"), "traffic_by_kernel": it.get("kernels"),
+                    "traffic_source": it.get("source"),
                     "algorithmic_bytes_per_path_sample": per_path, "segments_per_path": segs / paths,
                     "n_node_per_segment": nodes / segs, "n_tri_per_segment": tris_t / segs,
                     "note": "SURVEY 8(d)'s figure: algorithmic bytes (reference-rule visits counted by the oracle on sample 0 of every pixel) "
                             "over wall time. Most of it is node / triangle re-reads that L1 / L2 / Infinity Cache serve; the kernel that "
-                            "dominates (traversal, trace_share_of_device_time_rank0) is bound as the headline roofline says. Counter bytes "
-                            "of the integrator's kernels: profiles/ (pmc_integrator)",
+                            "dominates (traversal, trace_share_of_device_time_rank0) is bound as the headline roofline says. traffic = counter "
+                            "bytes of all the integrator's kernels for this render (per path-sample x paths; read side doubled, Infinity-Cache "
+                            "hits included), hbm_counter_frac = that over wall time and 8 TB/s",
                 }
         except Exception as e:  # oracle not built: keep the bench usable, say so
             cpu_baseline = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"unavailable: {type(e).__name__}: {e}"}
