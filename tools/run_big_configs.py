@@ -90,11 +90,18 @@ if not a.skip_20m:
     b_ray = 48 + 64 * n_node + 48 * n_tri
     brays, bstart = fi.bounce_rays(rays, hits)
     msb, _ = time_trace(gsc, brays, bstart)
+    other = {}
+    for mode, name in ((abi.PT_TRAVERSE_MIN_T, "min_t"), (abi.PT_TRAVERSE_REPLAY, "replay")):
+        ctx.set_traversal(mode)
+        m1, h1 = time_trace(gsc, rays, reps=4)
+        m2, _ = time_trace(gsc, brays, bstart, reps=4)
+        other[name] = {"Mrays_per_s": rays.size / m1 / 1e3, "bounce_Mrays_per_s": rays.size / m2 / 1e3, "ids_differing_from_default": int((h1["tri"] != hits["tri"]).sum())}
+    ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
     out = {"leg": f"config5 share: soup-{a.tris20} closest hit, 3840x2160 primaries", "gen_s": t_gen, "bvh_build_s": t_build,
            "bvh_depth": info.max_depth, "scene_device_bytes": info.device_bytes, "ms": ms, "Mrays_per_s": rays.size / ms / 1e3,
            "bounce_ms": msb, "bounce_Mrays_per_s": rays.size / msb / 1e3,
            "n_node": n_node, "n_tri": n_tri, "bytes_per_ray": b_ray, "algorithmic_GBps": b_ray * rays.size / ms / 1e6,
-           "hit_fraction": float((hits["tri"] != abi.PT_NO_TRIANGLE).mean())}
+           "hit_fraction": float((hits["tri"] != abi.PT_NO_TRIANGLE).mean()), "other_traversals": other}
     out.update(par)
     print(json.dumps(out), flush=True)
     d_img = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
