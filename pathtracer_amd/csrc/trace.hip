@@ -302,8 +302,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_mint_persistent(
 // distance); the launcher runs the REPLAY kernel over that list next.  Two counters alternate between calls like the
 // ticket words: this launch clears the one the next call uses.
 template <int S, bool QUEUED>
-// (waves_per_eu 4..5: with the default target of 6 the register allocator spills the ray's inverse direction to scratch and
-// reloads it at every record although the kernel then needs 72 VGPRs, which still fit six waves per SIMD)
+// (waves_per_eu 4..5: with the default target the register allocator spills the ray's inverse direction to scratch and
+// reloads it at every record, and with a target of six waves it still spills 16 bytes per lane - scratch stores reach HBM;
+// at five the kernel takes 80 VGPRs and no scratch, the descriptor admits five blocks per CU and the launcher asks for five)
 __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_trace_scoped_persistent(
     DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
