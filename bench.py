@@ -156,7 +156,7 @@ def main():
                "Mrays_per_s_per_gpu": n / float(np.mean(ms[2:])) / 1e3, "ids_differing_from_exact": int((alt_ids != d_hits[:, 0]).sum()),
                "note": "PT_TRAVERSE_MIN_T prunes against the best hit of the whole ray: a minimum-t hit, not the recursion's choice at ties (opt-in)"}
 
-    def render_leg(width, height, spp_total, begin, count, label):
+    def render_leg(width, height, spp_total, begin, count, label, mode=abi.PT_RENDER_SUM):
         """One sample-split render: this rank renders [begin, begin+count) into a SUM buffer, one all-reduce, finalize.  Timed
         between barriers, max over ranks."""
         d_img = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
@@ -164,7 +164,7 @@ def main():
         reduce_ms = [0.0]
 
         def render_sum(b, c):
-            ctx.render_dev(scene, width, height, b, c, spp_total, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
+            ctx.render_dev(scene, width, height, b, c, spp_total, 1, mode, d_img.data_ptr())
             return d_img
 
         def all_reduce(buf):
@@ -178,7 +178,7 @@ def main():
             dist.all_reduce(torch.zeros_like(d_img))
         # warm-up: one pass-sized call, so that the pass workspace (about 1.1 KiB per path in flight) is allocated before
         # the timed region
-        ctx.render_dev(scene, width, height, begin, min(count, max(1, (128 << 20) // (width * height))), spp_total, 1, abi.PT_RENDER_SUM, d_img.data_ptr())
+        ctx.render_dev(scene, width, height, begin, min(count, max(1, (128 << 20) // (width * height))), spp_total, 1, mode, d_img.data_ptr())
         sharding.finalize_sums(d_img.clone())       # first use of these torch kernels loads their code objects
         barrier()
         t1 = time.perf_counter()
@@ -206,6 +206,12 @@ def main():
             spectral, d_img = render_leg(a.width, a.height, spp_total, rank * a.spectral_spp, a.spectral_spp,
                                          "spectral spp/s at 1080p, 1M tris")
             spectral["scaling"] = "weak"
+            # the same leg with the opt-in extension that normalises the direction handed to the sky model: the reference does
+            # not (hosek_wilkie.rs:313-316 then makes NaN of most pixels, finite_pixel_fraction above), so "images match" on the
+            # faithful leg is largely NaN-mask equality; this one is finite everywhere
+            nrm, _ = render_leg(a.width, a.height, spp_total, rank * a.spectral_spp, a.spectral_spp, "spectral spp/s at 1080p, 1M tris, sky direction normalised",
+                                mode=abi.PT_RENDER_SUM | abi.PT_RENDER_NORMALIZE_SKY_DIRECTION)
+            spectral["normalized_sky_direction"] = {k: nrm[k] for k in ("value", "unit", "seconds", "finite_pixel_fraction", "segments_per_path")}
             spectral["config"] = {"workload": f"soup-{a.tris} + Hosek-Wilkie sky (turbidity 3, albedo 0.3), {a.width}x{a.height}, "
                                               f"{spp_total} spp, seed 1 (BASELINE configs[2]: 64 spp per GPU, samples split across ranks)",
                                   "traversal": a.traversal}

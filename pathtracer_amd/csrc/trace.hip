@@ -279,19 +279,19 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_mint_persistent(
                 }
                 cur = PTC_IDLE;
             }
-            // ---- phase 3: pop; an empty stack ends the ray ----
-            while (cur == PTC_IDLE) {
+            // ---- phase 3: ONE pop per trip (see k_trace_scoped_persistent); an empty stack ends the ray ----
+            if (cur == PTC_IDLE) {
                 if (st.empty()) {
                     out[ray_i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
                                             __float_as_uint(best_u), __float_as_uint(best_v));
                     has_ray = false;
-                    break;
+                } else {
+                    const uint2 e = st.pop(ring);
+                    const uint32_t height = st.size();
+                    const uint32_t changed = height < mark ? 1u : 0u;      // the best hit lies in this entry's near sibling
+                    mark = ptc_umin(mark, height);
+                    if ((int32_t)(__float_as_uint(best_t) - changed) >= (int32_t)e.y) cur = e.x;
                 }
-                const uint2 e = st.pop(ring);
-                const uint32_t height = st.size();
-                const uint32_t changed = height < mark ? 1u : 0u;      // the best hit lies in this entry's near sibling
-                mark = ptc_umin(mark, height);
-                if ((int32_t)(__float_as_uint(best_t) - changed) >= (int32_t)e.y) cur = e.x;
             }
         }
     }
@@ -364,9 +364,15 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
             if (tk.exhausted) break;
             continue;
         }
-        if (has_ray) {
+        // The three blocks below are executed by the wave whenever ANY lane needs them, so what each costs is set by how many
+        // lanes share an execution (tools/wave_sim.py replays the model's trip logs through this loop: the record step runs
+        // with ~54 of 64 lanes, the leaf test with ~12, and a pop loop iterated until the LAST lane had found an entry ran
+        // with ~8, four iterations per trip).  So a trip pops ONCE: a lane whose entry was not entered (or was a RESTORE)
+        // pops again on the next trip, beside the others' next record, instead of holding them up (+3 % on primaries, +6 %
+        // on bounce rays; two or three pops per trip, and making lanes wait at a leaf until 8-24 are there, were slower).
+        if (has_ray && !(cur & PTC_LEAF_BIT)) {
             // ---- phase 1: wide record = bvh.rs:259-325 at a binary node and at the child it enters ----
-            if (!(cur & PTC_LEAF_BIT)) {
+            {
                 PtcWideStep s;
                 // Sign-select form (trace_step.h) when every ray of the wave has a finite, non-zero inverse direction and the
                 // scene allows it: each lane loads the near planes (lo or hi by the sign of its inverse direction) and the far
@@ -394,8 +400,10 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                 if (s.v2) st.push(ring, s.ref2, __float_as_uint(s.e2));
                 cur = s.cur;
             }
-            // ---- phase 2: leaf (bvh.rs:327-336) ----
-            if ((cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
+        }
+        // ---- phase 2: leaf (bvh.rs:327-336) ----
+        {
+            if (has_ray && (cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
                 const uint32_t tri = cur & PTC_INDEX_MASK;
                 if (tri != skip) {
                     const float4* tp = sc.tris + (size_t)tri * 3u;
@@ -412,28 +420,30 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                 }
                 cur = PTC_IDLE;
             }
-            // ---- phase 3: pop; an empty stack ends the ray ----
-            while (has_ray && cur == PTC_IDLE) {
+        }
+        // ---- phase 3: pop; an empty stack ends the ray ----
+        {
+            if (has_ray && cur == PTC_IDLE) {
                 if (st.empty()) {
                     out[ray_i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
                                             __float_as_uint(best_u), __float_as_uint(best_v));
                     has_ray = false;
                     sign_ok = true;
-                    break;
-                }
-                const uint2 e = st.pop(ring);
-                const float ey = __uint_as_float(e.y);
-                const bool restore = e.x == PTC_RESTORE;                // {RESTORE, the enclosing scope's minimum so far}
-                const bool visit = !restore && m_cur > ey;             // first_distance > second_child_min (bvh.rs:285)
-                if (restore) m_cur = ey < m_cur ? ey : m_cur;
-                if (!restore && (e.x & PTC_COMPANION)) {                // the far child's other grandchild lies directly below
-                    const uint2 c = st.pop(ring);
-                    if (visit) {                                        // entering the far child: its far grandchild waits for the near one
-                        if (m_cur < pt_inf()) { st.push(ring, PTC_RESTORE, __float_as_uint(m_cur)); m_cur = pt_inf(); }
-                        st.push(ring, c.x, c.y);
+                } else {
+                    const uint2 e = st.pop(ring);
+                    const float ey = __uint_as_float(e.y);
+                    const bool restore = e.x == PTC_RESTORE;                // {RESTORE, the enclosing scope's minimum so far}
+                    const bool visit = !restore && m_cur > ey;             // first_distance > second_child_min (bvh.rs:285)
+                    if (restore) m_cur = ey < m_cur ? ey : m_cur;
+                    if (!restore && (e.x & PTC_COMPANION)) {                // the far child's other grandchild lies directly below
+                        const uint2 c = st.pop(ring);
+                        if (visit) {                                        // entering the far child: its far grandchild waits for the near one
+                            if (m_cur < pt_inf()) { st.push(ring, PTC_RESTORE, __float_as_uint(m_cur)); m_cur = pt_inf(); }
+                            st.push(ring, c.x, c.y);
+                        }
                     }
+                    if (visit) cur = e.x & ~PTC_COMPANION;
                 }
-                if (visit) cur = e.x & ~PTC_COMPANION;
             }
         }
     }
@@ -517,8 +527,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_replay_persistent(
                 }
                 descending = false;
             }
-            // ---- phase 3: return through the frames until one sends the lane down again ----
-            while (!descending) {
+            // ---- phase 3: return through ONE frame per trip (a lane still returning goes on next trip, beside the others' next
+            // node, instead of holding the wave in this block: see k_trace_scoped_persistent) ----
+            if (!descending) {
                 if (st.empty()) {
                     uint4 o = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
                     if (ret_id != PTC_NONE_ID) {
@@ -530,26 +541,26 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_replay_persistent(
                     }
                     out[ray_i] = o;
                     has_ray = false;
-                    break;
-                }
-                const uint2 e = st.pop(ring);
-                const bool is_b = ((e.x & PTC_FRAME_BIT) != 0u) && ((e.x & PTC_LEAF_BIT) == 0u);
-                if (!is_b) {
-                    // near subtree returned `ret`; bvh.rs:280-285
-                    const float first_distance = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
-                    if (first_distance > __uint_as_float(e.y)) {
-                        st.push(ring, PTC_FRAME_BIT | ret_id, __float_as_uint(ret_t));   // B frame keeps `first`
-                        cur = e.x;
-                        descending = true;
-                    }
-                    // else: return first_intersection unchanged (bvh.rs:304-306)
                 } else {
-                    // far subtree returned `ret`; bvh.rs:294-303
-                    const uint32_t f_id = e.x & PTC_INDEX_MASK;
-                    const float f_t = __uint_as_float(e.y);
-                    const float fd = (f_id != PTC_NONE_ID) ? f_t : pt_inf();
-                    const float sd = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
-                    if (fd < sd) { ret_id = f_id; ret_t = f_t; }
+                    const uint2 e = st.pop(ring);
+                    const bool is_b = ((e.x & PTC_FRAME_BIT) != 0u) && ((e.x & PTC_LEAF_BIT) == 0u);
+                    if (!is_b) {
+                        // near subtree returned `ret`; bvh.rs:280-285
+                        const float first_distance = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
+                        if (first_distance > __uint_as_float(e.y)) {
+                            st.push(ring, PTC_FRAME_BIT | ret_id, __float_as_uint(ret_t));   // B frame keeps `first`
+                            cur = e.x;
+                            descending = true;
+                        }
+                        // else: return first_intersection unchanged (bvh.rs:304-306)
+                    } else {
+                        // far subtree returned `ret`; bvh.rs:294-303
+                        const uint32_t f_id = e.x & PTC_INDEX_MASK;
+                        const float f_t = __uint_as_float(e.y);
+                        const float fd = (f_id != PTC_NONE_ID) ? f_t : pt_inf();
+                        const float sd = (ret_id != PTC_NONE_ID) ? ret_t : pt_inf();
+                        if (fd < sd) { ret_id = f_id; ret_t = f_t; }
+                    }
                 }
             }
         }

@@ -77,6 +77,10 @@ Wide make_wide(const pt_bvh_node* nodes, uint32_t i) {
 
 struct Entry { uint32_t ref; float e; };
 
+// optional per-trip log for tools/wave_sim.py: one byte per loop trip of every ray (bit 0: a record was visited, bit 1: a
+// triangle was tested or skipped as `start`, bits 2..7: entries popped after it), rays separated by 0xFF
+std::vector<uint8_t>* g_trip_log = nullptr;
+
 }  // namespace
 
 extern "C" {
@@ -121,7 +125,9 @@ int ptm_trace_scoped_trips(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_
         const uint64_t trips_before = stats[7];
         while (alive) {
             stats[7] += 1;
+            uint32_t log_bits = 0u, log_pops = 0u;
             if (!(cur & PTC_LEAF_BIT)) {
+                log_bits |= 1u;
                 const Wide& w = wide[cur];
                 stats[2] += 1;
                 PtcWideStep s;
@@ -151,6 +157,7 @@ int ptm_trace_scoped_trips(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_
                 cur = s.cur;
             }
             if ((cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
+                log_bits |= 2u;
                 const uint32_t tri = cur & PTC_INDEX_MASK;
                 if (tri != skip) {
                     stats[3] += 1;
@@ -167,6 +174,7 @@ int ptm_trace_scoped_trips(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_
                 if (st.empty()) { alive = false; break; }
                 const Entry e = st.back();
                 st.pop_back();
+                log_pops += 1u;
                 if (e.ref == PTC_RESTORE) { m_cur = e.e < m_cur ? e.e : m_cur; continue; }
                 const bool visit = m_cur > e.e;                      // first_distance > second_child_min (bvh.rs:285)
                 if (e.ref & PTC_COMPANION) {
@@ -176,11 +184,30 @@ int ptm_trace_scoped_trips(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_
                 }
                 if (visit) { cur = e.ref & ~PTC_COMPANION; stats[6] += 1; }
             }
+            if (g_trip_log) g_trip_log->push_back((uint8_t)(log_bits | ((log_pops < 62u ? log_pops : 62u) << 2)));
         }
+        if (g_trip_log) g_trip_log->push_back(0xFF);
         if (!flagged[i]) out[i] = pt_hit{best_id, best_id == PT_NO_TRIANGLE ? 0.0f : best_t, best_u, best_v};
         if (per_ray_trips) per_ray_trips[i] = (uint32_t)(stats[7] - trips_before);
     }
     return 0;
+}
+
+// trip log of the rays of one call (see g_trip_log): returns its length; `log` may be NULL to ask for the size of the last one
+uint64_t ptm_trace_scoped_log(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triangle* tris, uint32_t n_tris,
+                              const pt_ray* rays, const uint32_t* start, uint64_t n, uint8_t* log, uint64_t capacity) {
+    static std::vector<uint8_t> last;
+    if (rays) {
+        last.clear();
+        g_trip_log = &last;
+        std::vector<pt_hit> out(n);
+        std::vector<uint8_t> flagged(n);
+        uint64_t stats[8];
+        ptm_trace_scoped_trips(nodes, n_nodes, tris, n_tris, rays, start, n, out.data(), flagged.data(), stats, nullptr);
+        g_trip_log = nullptr;
+    }
+    if (log && capacity >= last.size()) std::memcpy(log, last.data(), last.size());
+    return last.size();
 }
 
 int ptm_trace_scoped(const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triangle* tris, uint32_t n_tris,
