@@ -47,6 +47,9 @@
 #ifndef PTC_SHARDS
 #define PTC_SHARDS 8u             /* ticket words / contiguous ray shards per launch (power of two not required) */
 #endif
+#ifndef PTC_POPS_PER_TRIP
+#define PTC_POPS_PER_TRIP 1
+#endif
 #define PTC_FIRST 64u              /* rays of a wave's static first block (one per lane) */
 
 namespace {
@@ -368,8 +371,9 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
         // lanes share an execution (tools/wave_sim.py replays the model's trip logs through this loop: the record step runs
         // with ~54 of 64 lanes, the leaf test with ~12, and a pop loop iterated until the LAST lane had found an entry ran
         // with ~8, four iterations per trip).  So a trip pops ONCE: a lane whose entry was not entered (or was a RESTORE)
-        // pops again on the next trip, beside the others' next record, instead of holding them up (+3 % on primaries, +6 %
-        // on bounce rays; two or three pops per trip, and making lanes wait at a leaf until 8-24 are there, were slower).
+        // pops again on the next trip, beside the others' next record, instead of holding them up (EXACT 1 727 -> 1 929 Mrays/s, bounce
+        // rays 1 485 -> 1 675; two pops per trip - PTC_POPS_PER_TRIP - or three, and making lanes wait at a leaf until 8-24
+        // are there, were slower or equal; so was touching the next record's line one trip early).
         if (has_ray && !(cur & PTC_LEAF_BIT)) {
             // ---- phase 1: wide record = bvh.rs:259-325 at a binary node and at the child it enters ----
             {
@@ -422,7 +426,8 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
             }
         }
         // ---- phase 3: pop; an empty stack ends the ray ----
-        {
+#pragma unroll
+        for (int rep = 0; rep < PTC_POPS_PER_TRIP; ++rep) {
             if (has_ray && cur == PTC_IDLE) {
                 if (st.empty()) {
                     out[ray_i] = make_uint4(best_id, __float_as_uint(best_id == PT_NO_TRIANGLE ? 0.0f : best_t),
