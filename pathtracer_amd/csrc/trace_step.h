@@ -183,43 +183,62 @@ struct PtcSlots {
     float nz0, fz0, nz1, fz1, nz2, fz2, nz3, fz3;
 };
 
+// The decisions of a record are boolean algebra over ten comparisons.  On the device a per-lane boolean IS a lane mask in a
+// scalar register pair, but LLVM canonicalises (c && a) || (!c && b) into a select of i1 and the backend lowers that through
+// 0 / 1 VGPRs (five VALU instructions per select, twenty per record).  So the device build does the algebra on the masks
+// themselves - ballot of a comparison is the comparison's own result register, and / or / andn2 are scalar instructions,
+// inverse ballot hands a mask back as a boolean - and the host build (the model of the CPU tests) on plain bools.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned long long PtcMask;
+#define PTC_B(x) __builtin_amdgcn_ballot_w64(x)
+#define PTC_NOT(m) (~(m))
+#define PTC_IB(m) __builtin_amdgcn_inverse_ballot_w64(m)
+#else
+typedef bool PtcMask;
+#define PTC_B(x) (x)
+#define PTC_NOT(m) (!(m))
+#define PTC_IB(m) (m)
+#endif
+
 template <class F4>
 PT_HD void ptc_wide_decide(const PtcSlots& q, F4 rw, PtcWideStep& s) {
     float k0, k1, k2, k3, kR, kL;
-    const bool h0 = ptc_close(q.nx0, q.fx0, q.ny0, q.fy0, q.nz0, q.fz0, k0);
-    const bool h1 = ptc_close(q.nx1, q.fx1, q.ny1, q.fy1, q.nz1, q.fz1, k1);
-    const bool h2 = ptc_close(q.nx2, q.fx2, q.ny2, q.fy2, q.nz2, q.fz2, k2);
-    const bool h3 = ptc_close(q.nx3, q.fx3, q.ny3, q.fy3, q.nz3, q.fz3, k3);
+    const PtcMask h0 = PTC_B(ptc_close(q.nx0, q.fx0, q.ny0, q.fy0, q.nz0, q.fz0, k0));
+    const PtcMask h1 = PTC_B(ptc_close(q.nx1, q.fx1, q.ny1, q.fy1, q.nz1, q.fz1, k1));
+    const PtcMask h2 = PTC_B(ptc_close(q.nx2, q.fx2, q.ny2, q.fy2, q.nz2, q.fz2, k2));
+    const PtcMask h3 = PTC_B(ptc_close(q.nx3, q.fx3, q.ny3, q.fy3, q.nz3, q.fz3, k3));
     // the children's own boxes (joins of their slots), bvh.rs:260-261 at X
-    const bool hR = ptc_close(ptc_min(q.nx0, q.nx1), ptc_max(q.fx0, q.fx1), ptc_min(q.ny0, q.ny1), ptc_max(q.fy0, q.fy1),
+    const bool bR = ptc_close(ptc_min(q.nx0, q.nx1), ptc_max(q.fx0, q.fx1), ptc_min(q.ny0, q.ny1), ptc_max(q.fy0, q.fy1),
                               ptc_min(q.nz0, q.nz1), ptc_max(q.fz0, q.fz1), kR);
-    const bool hL = ptc_close(ptc_min(q.nx2, q.nx3), ptc_max(q.fx2, q.fx3), ptc_min(q.ny2, q.ny3), ptc_max(q.fy2, q.fy3),
+    const bool bL = ptc_close(ptc_min(q.nx2, q.nx3), ptc_max(q.fx2, q.fx3), ptc_min(q.ny2, q.ny3), ptc_max(q.fy2, q.fy3),
                               ptc_min(q.nz2, q.nz3), ptc_max(q.fz2, q.fz3), kL);
+    const PtcMask hR = PTC_B(bR), hL = PTC_B(bL);
     const uint32_t r0 = pt_f2u(rw.x), r1 = pt_f2u(rw.y), r2 = pt_f2u(rw.z), r3 = pt_f2u(rw.w);
-    // inside each child: left = the odd slot, right = the even one; left first iff l_min < r_min (bvh.rs:266).
-    // (conditions are kept as boolean algebra, not as selects between booleans: lane masks stay in scalar registers)
-    const bool Rl = h1 && (k1 < k0 || !h0), Ll = h3 && (k3 < k2 || !h2);
+    // inside each child: left = the odd slot, right = the even one; left first iff l_min < r_min (bvh.rs:266)
+    const PtcMask mRl = h1 & (PTC_B(k1 < k0) | PTC_NOT(h0)), mLl = h3 & (PTC_B(k3 < k2) | PTC_NOT(h2));
+    const bool Rl = PTC_IB(mRl), Ll = PTC_IB(mLl);
     const uint32_t Rnear = Rl ? r1 : r0, Rfar = Rl ? r0 : r1, Lnear = Ll ? r3 : r2, Lfar = Ll ? r2 : r3;
     const float Rfar_e = Rl ? k0 : k1, Lfar_e = Ll ? k2 : k3;
-    const bool Rboth = h0 && h1, Lboth = h2 && h3, Rany = h0 || h1, Lany = h2 || h3;
+    const PtcMask Rboth = h0 & h1, Lboth = h2 & h3, Rany = h0 | h1, Lany = h2 | h3;
     // at X
-    const bool both = hL && hR, any = hL || hR;
-    const bool nearL = hL && (kL < kR || !hR);
-    const bool Nany = (nearL && Lany) || (!nearL && Rany), Nboth = (nearL && Lboth) || (!nearL && Rboth);
-    const bool Fany = (nearL && Rany) || (!nearL && Lany), Fboth = (nearL && Rboth) || (!nearL && Lboth);
-    s.v0 = both && Fboth;
+    const PtcMask both = hL & hR, any = hL | hR;
+    const PtcMask mNearL = hL & (PTC_B(kL < kR) | PTC_NOT(hR)), mNearR = PTC_NOT(mNearL);
+    const PtcMask Nany = (mNearL & Lany) | (mNearR & Rany), Nboth = (mNearL & Lboth) | (mNearR & Rboth);
+    const PtcMask Fany = (mNearL & Rany) | (mNearR & Lany), mFboth = (mNearL & Rboth) | (mNearR & Lboth);
+    const bool nearL = PTC_IB(mNearL), Fboth = PTC_IB(mFboth);
+    s.v0 = PTC_IB(both & mFboth);
     s.ref0 = nearL ? Rfar : Lfar;
     s.e0 = nearL ? Rfar_e : Lfar_e;
-    s.v1 = both && Fany;
+    s.v1 = PTC_IB(both & Fany);
     const uint32_t fnear = nearL ? Rnear : Lnear;
     s.ref1 = Fboth ? (fnear | PTC_COMPANION) : fnear;
     s.e1 = nearL ? kR : kL;
-    s.v2 = any && Nboth;
+    s.v2 = PTC_IB(any & Nboth);
     s.ref2 = nearL ? Lfar : Rfar;
     s.e2 = nearL ? Lfar_e : Rfar_e;
     const uint32_t nnear = nearL ? Lnear : Rnear;
-    s.cur = (any && Nany) ? nnear : PTC_IDLE;
-    s.hit_l = hL; s.hit_r = hR; s.entry_l = kL; s.entry_r = kR;
+    s.cur = PTC_IB(any & Nany) ? nnear : PTC_IDLE;
+    s.hit_l = bL; s.hit_r = bR; s.entry_l = kL; s.entry_r = kR;
 }
 
 // General form: any REGULAR ray.  (near, far) per axis = (minNum, maxNum) of the two plane distances, as bvh.rs:394-401.
