@@ -18,9 +18,14 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--leaf-order", action="store_true", help="experiment: hand the triangles over in the order of the BVH's leaves (rebuilt on the permuted array)")
 a = ap.parse_args()
 
 arr = workloads.soup_scene(a.tris, sky=workloads.hw_sky())
+if a.leaf_order:
+    order = arr.nodes["shape_index"][arr.nodes["is_leaf"] != 0]
+    t2 = np.ascontiguousarray(arr.triangles[order])
+    arr = abi.SceneArrays(t2, core.bvh_build(t2), arr.materials, arr.sky)
 ctx = core.Context(0)
 sc = ctx.scene(arr)
 d_img = torch.zeros((a.height, a.width, 4), dtype=torch.float32, device="cuda")

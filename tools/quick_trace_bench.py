@@ -23,10 +23,15 @@ ap.add_argument("--sort", choices=["none", "origin", "origin+octant", "octant"],
                 help="with --bounce: reorder the secondary rays by a 30-bit Morton key of the origin and/or the direction octant")
 ap.add_argument("--device-only", action="store_true", help="skip the host-pointer entry point")
 ap.add_argument("--tile", type=int, default=0, help="reorder rays into TxT pixel tiles")
+ap.add_argument("--leaf-order", action="store_true", help="experiment: hand the triangles over in the order of the BVH's leaves (rebuilt on the permuted array)")
 a = ap.parse_args()
 
 t = time.time()
 arr = workloads.soup_scene(a.tris)
+if a.leaf_order:
+    order = arr.nodes["shape_index"][arr.nodes["is_leaf"] != 0]
+    t2 = np.ascontiguousarray(arr.triangles[order])
+    arr = abi.SceneArrays(t2, core.bvh_build(t2), arr.materials, arr.sky)
 print(f"scene built in {time.time()-t:.2f}s", flush=True)
 ctx = core.Context(0)
 sc = ctx.scene(arr)
