@@ -118,6 +118,7 @@ struct pt_ctx {
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the EXACT traversal kernel (8, 12 or 16)
     uint32_t tune_host_chunk = 1u << 20;   // pt_trace_closest: rays per pipelined chunk
     uint32_t tune_pass_paths = 128u << 20; // pt_render: paths in flight (~1.1 KiB of HBM each)
+    size_t   tune_work_limit = 0;          // pt_render: workspace bytes it may reserve (0: what hipMalloc gives); beyond it the pass is halved, as when HBM is short
     uint32_t tune_pass_slots = 2;          // pt_render: passes in flight (1..4) of a render that does not fit in one
     float    tune_admit_frac = 0.25f;      // pt_render: the next pass joins when <= this fraction of a pass's paths is live
 };

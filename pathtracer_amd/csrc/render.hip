@@ -441,7 +441,8 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
         o_cnt = carve(256);
         o_verts = carve(N * PTC_MAX_VERTS * 2 * PTC_NW * sizeof(float));
         int rc = PT_ERR_NOMEM;
-        if (N <= (1ull << 30)) rc = ptc_reserve(ctx, &ctx->work, &ctx->work_bytes, off, "render workspace");
+        if (N <= (1ull << 30) && (ctx->tune_work_limit == 0u || off <= ctx->tune_work_limit))
+            rc = ptc_reserve(ctx, &ctx->work, &ctx->work_bytes, off, "render workspace");
         if (rc == PT_OK) break;
         if (rc != PT_ERR_NOMEM || (spp_pass == 1u && slots <= 1u)) return rc == PT_ERR_NOMEM && ctx->error.empty() ? ptc_fail(ctx, rc, "pt_render_dev: render workspace does not fit") : rc;
         if (spp_pass > 1u) spp_pass = (spp_pass + 1u) / 2u;

@@ -86,6 +86,31 @@ def test_config3_image_is_the_same_when_cut_into_many_passes(monkeypatch, golden
         ctx.close()
 
 
+def test_short_of_memory_the_pass_is_halved_not_the_image(monkeypatch, golden):
+    """When the workspace for the path budget does not fit, pt_render halves the pass until it does (one sample of every
+    pixel is the floor, then fewer slots), and fails with PT_ERR_NOMEM only when not even that fits.  PTC_WORK_LIMIT_MB
+    stands in for an HBM that is nearly full: 64 spp of 240x135 want 2.3 GB in one pass."""
+    meta, npz = golden
+    arr = workloads.soup_scene(1_000_000, sky=workloads.hw_sky())
+    for limit_mb, ok in ((256, True), (80, True), (8, False)):
+        monkeypatch.setenv("PTC_WORK_LIMIT_MB", str(limit_mb))
+        ctx = core.Context(0)
+        try:
+            sc = ctx.scene(arr)
+            if ok:
+                got = ctx.render(sc, 240, 135, 0, 64, 64, seed=1)
+                assert same_image(got, npz["config3_240x135_64spp"]), limit_mb
+                assert ctx.stats().paths == 240 * 135 * 64 and ctx.stats().trace_launches > 2 * 18        # several passes
+            else:
+                with pytest.raises(core.PtError) as e:
+                    ctx.render(sc, 240, 135, 0, 64, 64, seed=1)
+                assert e.value.code == abi.PT_ERR_NOMEM
+                assert ctx.trace(sc, core.gen_primary_rays(16, 16)).size == 256                         # the context is still usable
+            sc.close()
+        finally:
+            ctx.close()
+
+
 def test_config4_sample_ranges_at_3840x2160(gpu_ctx, soup1m_hw, golden):
     meta, npz = golden
     arr, sc = soup1m_hw
