@@ -212,6 +212,19 @@ def test_render_halves_its_pass_when_hbm_is_short(gpu_ctx):
         torch.cuda.empty_cache()
 
 
+def test_edge_sizes_of_a_render(oracle, gpu_ctx):
+    """No samples at all (a rank whose share of the samples is empty): zero sums, zero weight, no kernel of the path loop runs.
+    One pixel; one sample; an image narrower than a wave."""
+    arr = workloads.box_scene()
+    sc, osc = gpu_ctx.scene(arr), oracle.scene(arr)
+    img = gpu_ctx.render(sc, 40, 30, 5, 0, 8, seed=3, mode=abi.PT_RENDER_SUM)
+    assert img.shape == (30, 40, 4) and not img.any() and gpu_ctx.stats().paths == 0 and gpu_ctx.stats().trace_launches == 0
+    for w, h, spp in ((1, 1, 1), (1, 1, 9), (3, 2, 4), (70, 1, 2)):
+        got = gpu_ctx.render(sc, w, h, 0, spp, spp, seed=6)
+        want = oracle.render(osc, w, h, 0, spp, spp, seed=6)
+        compare_images(got, want, f"{w}x{h}x{spp}", max_diff_frac=0.0, mean_rel=0.0)
+
+
 def test_randomised_parity_sweep():
     """tools/fuzz_parity.py on a dozen seeds (the long runs are under profiles/): random degenerate / duplicated geometry,
     random rays, textures, normals, skies, cameras; every traversal mode on both trees, renders in EXACT and WIDE."""
