@@ -61,7 +61,18 @@ struct PassState {
     uint32_t  N;          // slots * cap: the path id space
     uint32_t  npix;
     uint32_t  sample_base[PTC_MAX_SLOTS];   // first sample index of the pass in each slot
+    uint32_t  group[PTC_MAX_SLOTS];         // samples of one pixel that sit side by side in the path ids of the slot's pass
 };
+
+// Path j of a pass <-> (pixel, sample of the pass): the samples of a pixel come in groups of G consecutive path ids, group
+// after group of all pixels: j = (s / G) * (npix * G) + pixel * G + s % G.  G = 1 is sample-major (a wave = 64 neighbouring
+// pixels of one sample); G = 16 makes a wave 4 pixels x 16 samples.
+__device__ __forceinline__ void path_to_pixel_sample(const PassState& st, uint32_t slot, uint32_t j, uint32_t& pixel, uint32_t& s) {
+    const uint32_t G = st.group[slot], span = st.npix * G;
+    const uint32_t blk = j / span, r = j - blk * span;
+    pixel = r / G;
+    s = blk * G + (r - pixel * G);
+}
 
 __device__ __forceinline__ uint32_t slot_of(const PassState& st, uint32_t p) {
     return (uint32_t)(p >= st.cap) + (uint32_t)(p >= 2u * st.cap) + (uint32_t)(p >= 3u * st.cap);   // cap <= 2^28
@@ -97,8 +108,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera 
     const uint32_t j = blockIdx.x * PTC_BLOCK + threadIdx.x;
     if (j >= n) return;
     const uint32_t p = slot * st.cap + j;
-    const uint32_t pixel = j % st.npix;
-    const uint32_t sample = st.sample_base[slot] + j / st.npix;
+    uint32_t pixel, s_local;
+    path_to_pixel_sample(st, slot, j, pixel, s_local);
+    const uint32_t sample = st.sample_base[slot] + s_local;
     const uint32_t px = pixel % cam.width, py = pixel / cam.width;
     pt_rng rng;
     pt_rng_init(&rng, seed, pixel, sample, 0u);
@@ -191,7 +203,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
             pt_rng rng;
             const uint32_t slot = slot_of(st, p), j = p - slot * st.cap;
             in_watched = slot == watch_slot;
-            pt_rng_init(&rng, seed, j % st.npix, st.sample_base[slot] + j / st.npix, state.x);
+            uint32_t pixel, s_local;
+            path_to_pixel_sample(st, slot, j, pixel, s_local);
+            pt_rng_init(&rng, seed, pixel, st.sample_base[slot] + s_local, state.x);
             float dis = m.dissolve_value;
             if (m.dissolve_img != 0xFFFFFFFFu) {
                 float g, b; const float flat[3] = {dis, dis, dis};
@@ -331,39 +345,59 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky
 }
 
 // ---- accumulate: fold + CMF + pixel sum (scene.rs:371-373, main.rs:93-97) -----------------------------
+// A block takes 256 consecutive path ids of one sample group = 256 / G pixels x G samples (coalesced reads of the path state and
+// of the vertex records), every thread folds ITS path back to front and weights it with the CMF, the 24 terms go through LDS,
+// and the first thread of each pixel adds them to the pixel in sample order, wavelength by wavelength - the additions and
+// their order are those of main.rs:93-97 whatever G is.  The block then moves on to the same pixels' next sample group.
 __global__ __launch_bounds__(PTC_BLOCK) void k_accumulate(PassState st, uint32_t slot, uint32_t spp_pass, float4* __restrict__ acc) {
-    const uint32_t pixel = blockIdx.x * PTC_BLOCK + threadIdx.x;
-    if (pixel == 0u) st.counts[6] = 0u;               // the k_sky before this kernel has consumed the miss list
-    if (pixel >= st.npix) return;
-    float4 a = acc[pixel];
-    for (uint32_t s = 0; s < spp_pass; ++s) {
-        const uint32_t p = slot * st.cap + s * st.npix + pixel;
-        const uint32_t sy = st.state[p].y;
-        const uint32_t len = PTC_STATE_LEN(sy), emask = PTC_STATE_EMASK(sy);
-        const float hero = st.rays[2u * p + 1u].w;
-        float L[PTC_NW];
+    __shared__ float terms[PTC_BLOCK][3 * PTC_NW + 1];        // + 1: threads of a wave start in different banks
+    if (blockIdx.x == 0u && threadIdx.x == 0u) st.counts[6] = 0u;      // the k_sky before this kernel has consumed the miss list
+    const uint32_t G = st.group[slot];                        // a power of two <= 64 that divides spp_pass
+    const uint32_t per_block = PTC_BLOCK / G;
+    const uint32_t local = threadIdx.x / G, g = threadIdx.x - local * G;
+    const uint32_t pixel = blockIdx.x * per_block + local;
+    const bool live = pixel < st.npix, owner = live && g == 0u;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (owner) a = acc[pixel];
+    for (uint32_t blk = 0; blk * G < spp_pass; ++blk) {
+        if (live) {
+            const uint32_t p = slot * st.cap + blk * (st.npix * G) + pixel * G + g;
+            const uint32_t sy = st.state[p].y;
+            const uint32_t len = PTC_STATE_LEN(sy), emask = PTC_STATE_EMASK(sy);
+            const float hero = st.rays[2u * p + 1u].w;
+            float L[PTC_NW];
 #pragma unroll
-        for (int i = 0; i < PTC_NW; ++i) L[i] = 0.0f;
-        for (uint32_t k = len; k-- > 0u;) {
-            const float4* v = weight_ptr(st, p, k);
-            const float4 w0 = v[0], w1 = v[1];
-            float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0;      // Emit::Null samples to 0 (material.rs:187)
-            if ((emask >> k) & 1u) { const float4* ev = emit_ptr(st, p, k); e0 = ev[0]; e1 = ev[1]; }
-            L[0] = L[0] * w0.x + e0.x; L[1] = L[1] * w0.y + e0.y; L[2] = L[2] * w0.z + e0.z; L[3] = L[3] * w0.w + e0.w;
-            L[4] = L[4] * w1.x + e1.x; L[5] = L[5] * w1.y + e1.y; L[6] = L[6] * w1.z + e1.z; L[7] = L[7] * w1.w + e1.w;
-        }
-        float wl[PTC_NW];
-        ptc::wavelengths(hero, wl);
+            for (int i = 0; i < PTC_NW; ++i) L[i] = 0.0f;
+            for (uint32_t k = len; k-- > 0u;) {
+                const float4* v = weight_ptr(st, p, k);
+                const float4 w0 = v[0], w1 = v[1];
+                float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0;      // Emit::Null samples to 0 (material.rs:187)
+                if ((emask >> k) & 1u) { const float4* ev = emit_ptr(st, p, k); e0 = ev[0]; e1 = ev[1]; }
+                L[0] = L[0] * w0.x + e0.x; L[1] = L[1] * w0.y + e0.y; L[2] = L[2] * w0.z + e0.z; L[3] = L[3] * w0.w + e0.w;
+                L[4] = L[4] * w1.x + e1.x; L[5] = L[5] * w1.y + e1.y; L[6] = L[6] * w1.z + e1.z; L[7] = L[7] * w1.w + e1.w;
+            }
+            float wl[PTC_NW];
+            ptc::wavelengths(hero, wl);
 #pragma unroll
-        for (int i = 0; i < PTC_NW; ++i) {
-            float X, Y, Z;
-            ptc::from_wavelength(wl[i], X, Y, Z);
-            a.x += X * L[i] * (1.0f / (float)PTC_NW);
-            a.y += Y * L[i] * (1.0f / (float)PTC_NW);
-            a.z += Z * L[i] * (1.0f / (float)PTC_NW);
+            for (int i = 0; i < PTC_NW; ++i) {
+                float X, Y, Z;
+                ptc::from_wavelength(wl[i], X, Y, Z);
+                terms[threadIdx.x][3 * i + 0] = X * L[i] * (1.0f / (float)PTC_NW);
+                terms[threadIdx.x][3 * i + 1] = Y * L[i] * (1.0f / (float)PTC_NW);
+                terms[threadIdx.x][3 * i + 2] = Z * L[i] * (1.0f / (float)PTC_NW);
+            }
         }
+        __syncthreads();
+        if (owner) {
+            for (uint32_t s = 0; s < G; ++s) {
+                const float* t = terms[threadIdx.x + s];
+#pragma unroll
+                for (int i = 0; i < PTC_NW; ++i) { a.x += t[3 * i + 0]; a.y += t[3 * i + 1]; a.z += t[3 * i + 2]; }
+            }
+        }
+        __syncthreads();
     }
-    acc[pixel] = a;
+    if (owner) acc[pixel] = a;
 }
 
 // main.rs:100-107 (FINAL) or raw sums (SUM)
@@ -486,6 +520,8 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
         const uint32_t this_spp = std::min(spp_pass, spp_count - generated);
         const uint32_t P = this_spp * npix;
         st.sample_base[next_slot] = spp_begin + generated;
+        st.group[next_slot] = 1u;
+        for (uint32_t g = ctx->tune_sample_group; g > 1u; g >>= 1) if (this_spp % g == 0u) { st.group[next_slot] = g; break; }
         hipLaunchKernelGGL(k_generate, dim3((P + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, st, *cam, seed, next_slot, P, enq % 3u, enq & 1u);
         hipLaunchKernelGGL(k_admit, dim3(1), dim3(64), 0, s, st.counts, enq % 3u, P, n_fifo == 0u ? 1u : 0u);
         if (n_fifo == 0u) watch_since = enq;
@@ -502,7 +538,7 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
             hipLaunchKernelGGL(k_sky, dim3(sky_blocks), dim3(PTC_BLOCK), 0, s, scene->view, scene->d_sky, st, normalize_sky);
             sky_done = true;
         }
-        hipLaunchKernelGGL(k_accumulate, dim3(pix_blocks), dim3(PTC_BLOCK), 0, s, st, fifo[0].slot, fifo[0].spp, acc);
+        hipLaunchKernelGGL(k_accumulate, dim3((npix + PTC_BLOCK / st.group[fifo[0].slot] - 1) / (PTC_BLOCK / st.group[fifo[0].slot])), dim3(PTC_BLOCK), 0, s, st, fifo[0].slot, fifo[0].spp, acc);
         for (uint32_t i = 1; i < n_fifo; ++i) fifo[i - 1] = fifo[i];
         n_fifo -= 1u;
         watch_since = enq;                                // k_shade launches from now on watch the new front
