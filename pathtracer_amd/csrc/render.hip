@@ -7,7 +7,9 @@
 //   material.rs:255-297  Material::sample (dissolve test, normal, Lambert sphere offset, emission)
 //
 // One PASS renders `spp_pass` consecutive sample indices of every pixel at once.  Up to PTC_MAX_SLOTS passes are in
-// flight together, each in its own SLOT of the workspace: path id p = slot * cap + s_local * (W*H) + pixel.  When the
+// flight together, each in its own SLOT of the workspace: path id p = slot * cap + position in the pass, where the samples
+// of a pixel sit side by side in groups of up to 16 (path_to_pixel_sample below), so that a traversal wave holds a few
+// pixels' worth of samples: rays that start together.  When the
 // live paths of the passes in flight have thinned out, the next pass is generated into a free slot and its paths are
 // appended to the same queue, so that a traversal launch never holds only the thin tail of one pass (the last ten of
 // a pass's ~18 iterations hold < 3 % of its paths and cost a ray's latency each).  A pass is folded into the image
