@@ -115,6 +115,7 @@ static int pt_init_body(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_pass_paths = std::max(1u << 16, std::min(192u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
     ctx->tune_work_limit = (size_t)env_u32("PTC_WORK_LIMIT_MB", 0u) << 20;
     ctx->tune_sample_group = std::max(1u, std::min(64u, env_u32("PTC_SAMPLE_GROUP", ctx->tune_sample_group)));
+    while (ctx->tune_sample_group & (ctx->tune_sample_group - 1u)) ctx->tune_sample_group &= ctx->tune_sample_group - 1u;   // a power of two: k_accumulate cuts its 256 threads into groups
     ctx->tune_pass_slots = std::max(1u, std::min(4u, env_u32("PTC_PASS_SLOTS", ctx->tune_pass_slots)));
     ctx->tune_admit_frac = std::min(1.0f, (float)env_u32("PTC_ADMIT_PERCENT", (uint32_t)(ctx->tune_admit_frac * 100.0f + 0.5f)) / 100.0f);
     guard.p = nullptr;

@@ -57,6 +57,29 @@ def test_config3_full_frame_sample_and_64spp_image(gpu_ctx, soup1m_hw, golden):
     assert st.paths == 240 * 135 * 64 and st.segments > 3 * st.paths
 
 
+@pytest.mark.parametrize("group", [1, 2, 12, 64])
+def test_config3_image_does_not_depend_on_how_samples_are_grouped(monkeypatch, golden, group):
+    """PTC_SAMPLE_GROUP: how many samples of a pixel sit side by side in the path ids (which rays share a traversal wave, and how
+    k_accumulate cuts its blocks).  12 is not a power of two and becomes 8."""
+    meta, npz = golden
+    monkeypatch.setenv("PTC_SAMPLE_GROUP", str(group))
+    ctx = core.Context(0)
+    try:
+        sc = ctx.scene(workloads.soup_scene(1_000_000, sky=workloads.hw_sky()))
+        assert same_image(ctx.render(sc, 240, 135, 0, 64, 64, seed=1), npz["config3_240x135_64spp"])
+        a = ctx.render(sc, 61, 37, 3, 12, 64, seed=5, mode=abi.PT_RENDER_SUM)        # 12 samples from the 4th on, odd image size
+        monkeypatch.setenv("PTC_SAMPLE_GROUP", "1")
+        ref = core.Context(0)
+        try:
+            b = ref.render(ref.scene(workloads.soup_scene(1_000_000, sky=workloads.hw_sky())), 61, 37, 3, 12, 64, seed=5, mode=abi.PT_RENDER_SUM)
+        finally:
+            ref.close()
+        assert same_image(a, b)
+        sc.close()
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("slots,admit", [(1, 25), (2, 25), (3, 25), (4, 100), (3, 0)])
 def test_config3_image_is_the_same_when_cut_into_many_passes(monkeypatch, golden, slots, admit):
     """PTC_PASS_PATHS = 129 600 paths in flight: the 64 spp of the 240x135 frame become passes of 4 / slots samples, up to
