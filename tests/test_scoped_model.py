@@ -92,3 +92,23 @@ def test_underflow_and_non_finite_class(model, oracle):
     flagged, stats = check(model, oracle, arr, rays, what="underflow")
     want = oracle.trace(oracle.scene(arr), rays)
     assert flagged[~np.isfinite(want["t"])].all() and 0.02 < flagged.mean() < 0.2
+
+
+def test_trip_log_agrees_with_the_counters(model):
+    """tools/wave_sim.py replays the model's per-trip log; the log must tell the same story as the model's counters: one record
+    bit per record visited, one leaf bit per leaf reached, one pop per entry popped, a 0xFF after every ray."""
+    L = C.CDLL(LIB)
+    L.ptm_trace_scoped_log.restype = C.c_uint64
+    L.ptm_trace_scoped_log.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    arr = workloads.soup_scene(20_000)
+    rays = np.ascontiguousarray(core.gen_primary_rays(96, 54))
+    n = L.ptm_trace_scoped_log(abi.ptr(arr.nodes), arr.nodes.size, abi.ptr(arr.triangles), arr.triangles.size, abi.ptr(rays), None, rays.size, None, 0)
+    log = np.zeros(n, dtype=np.uint8)
+    assert L.ptm_trace_scoped_log(None, 0, None, 0, None, None, 0, abi.ptr(log), n) == n
+    _, flagged, stats = model(arr, rays)
+    assert not flagged.any()
+    trips = log[log != 0xFF]
+    assert (log == 0xFF).sum() == rays.size and trips.size == stats[7]
+    assert int((trips & 1).sum()) == stats[2]                      # records visited
+    assert int(((trips >> 1) & 1).sum()) == stats[3]               # triangle tests (no start triangles here)
+    assert stats[6] <= int((trips >> 2).sum()) <= stats[5]         # pops: at least the entries entered, at most the entries pushed (a COMPANION's partner rides along with it)
