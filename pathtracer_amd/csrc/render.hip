@@ -45,17 +45,24 @@
 namespace {
 
 struct PassState {
-    float4*   rays;       // [N][2]  {origin.xyz, bits(start triangle)}, {direction.xyz, hero wavelength offset}:
-                          //         pt_ray layout with the two pads in use; trace.hip reads the start from pad0
-    uint4*    hits;       // [N]
-    uint2*    state;      // [N]  {draws consumed so far by the path's stream, len (5 bits) | iterations << 5 (11 bits) |
-                          //       emit mask << 16: bit k set = vertex k carries an emission term}
+    // LIVE paths are addressed by POSITION, not by path id: every iteration's k_shade writes the ray and state of each
+    // survivor into the other of two buffers, at (first queue index of its span) + (its rank among the span's survivors),
+    // so the survivors of a span are neighbours in memory and the next iteration's traversal and shading read runs of
+    // whole cache lines however few of the pass's paths are still alive (by path id, every array cost one 128-byte
+    // request per path and kernel from the third iteration on).  The queues hold positions.
+    float4*   pray[2];    // [CAP][2]  {origin.xyz, bits(start triangle)}, {direction.xyz, hero wavelength offset}:
+                          //           pt_ray layout with the two pads in use; trace.hip reads the start from pad0
+    uint4*    pmeta[2];   // [CAP]     {path id, draws consumed so far by the path's stream, len (5 bits) | iterations << 5
+                          //            (11 bits) | emit mask << 16 (bit k set = vertex k carries an emission term), -}
+    uint4*    hits;       // [CAP]     by position, written by the traversal of the iteration
+    float4*   tail;       // [N][2]    by path id, written when the path ENDS: {last direction.xyz, hero}, {bits(state word), -, -, -}
+                          //           - what k_sky and k_accumulate need
     float4*   verts;      // weights [16][N][2] then emits [16][N][2]: vertex k of path p = {weight[0..3], weight[4..7]} and
                           //         {emit[0..3], emit[4..7]}, vertex-major so that the lanes of an iteration (k_shade) and the
                           //         neighbouring pixels of a sample (k_accumulate) touch neighbouring 32-byte records; the emit
                           //         record is only written and read where the state's emit mask says so (7 of 8 soup materials
                           //         emit nothing)
-    uint32_t* queue[2];   // [N] each
+    uint32_t* queue[2];   // [N] each: positions of the live paths
     uint32_t* miss_queue; // [N] paths whose ray left the scene since the last k_sky
     uint32_t* counts;     // [8]: three rotating pairs {live paths, live paths of the watched slot} at [2c], [2c + 1]
                           //      (iteration i reads pair i%3, fills pair (i+1)%3, clears pair (i+2)%3); [6] = length of miss_queue
@@ -126,10 +133,14 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_generate(PassState st, pt_camera 
     const float dy = -((y + 0.5f) * sy - 0.5f) * sensor1;
     const float dz = -cam.focal_length;
     const float hero = pt_rng_uniform(&rng, 0.0f, pt_uniform_scale(0.0f, (830.0f - 360.0f) / (float)PTC_NW));  // main.rs:83-84
-    st.rays[2u * p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PT_NO_TRIANGLE));
-    st.rays[2u * p + 1u] = make_float4(dx, dy, dz, hero);
-    st.state[p] = make_uint2(rng.index, 0u);
-    st.queue[qsel][st.counts[2u * c] + j] = p;
+    // positions: behind whatever the last iteration's k_shade may have written into this buffer (it wrote below the length
+    // of ITS queue, counter pair c - 1, rounded up to a span)
+    const uint32_t prev = st.counts[2u * ((c + 2u) % 3u)];
+    const uint32_t pos = (prev + PTC_SHADE_SPAN - 1u) / PTC_SHADE_SPAN * PTC_SHADE_SPAN + j;
+    st.pray[qsel][2u * (size_t)pos] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(PT_NO_TRIANGLE));
+    st.pray[qsel][2u * (size_t)pos + 1u] = make_float4(dx, dy, dz, hero);
+    st.pmeta[qsel][pos] = make_uint4(p, rng.index, 0u, 0u);
+    st.queue[qsel][st.counts[2u * c] + j] = pos;
 }
 __global__ void k_admit(uint32_t* counts, uint32_t c, uint32_t n, uint32_t watched) {
     if (threadIdx.x == 0u && blockIdx.x == 0u) {
@@ -166,27 +177,31 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
     for (uint32_t k0 = span0; k0 < span0 + PTC_SHADE_SPAN && k0 < count; k0 += PTC_BLOCK) {
         const uint32_t k = k0 + threadIdx.x;
         const bool active = k < count;
-        const uint32_t p = active ? st.queue[cur][k] : 0u;
-        uint4 hit = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
-        if (active) hit = st.hits[p];
+        const uint32_t pos = active ? st.queue[cur][k] : 0u;
+        uint4 hit = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u), meta = make_uint4(0u, 0u, 0u, 0u);
+        // new_d starts as the path's direction and new_state as its state: what a path that passes straight through, or
+        // ends at the sky, carries on (and no second copy of them is held in registers across the body)
+        float4 new_d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (active) { hit = st.hits[pos]; meta = st.pmeta[cur][pos]; new_d = st.pray[cur][2u * (size_t)pos + 1u]; }
+        const uint32_t p = meta.x;
         // miss: the path ends with {0, sky} (scene.rs:362-367); the sky term is evaluated by k_sky, once
         // per pass over all such paths, so that this kernel's lanes do not wait for it
         const bool missed = active && hit.x == PT_NO_TRIANGLE;
         const bool shading = active && !missed;
 
-        bool cont = false, put_vertex = false, put_dir = false, has_emit = false, in_watched = false;
+        bool cont = false, put_vertex = false, has_emit = false, in_watched = false;
         float weight[PTC_NW], emit[PTC_NW];
-        float4 new_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), new_d = new_o;
-        uint2 new_state = make_uint2(0u, 0u);
+        float4 new_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint2 new_state = make_uint2(meta.y, meta.z);
         uint32_t vslot = 0u;
 #pragma unroll
         for (int i = 0; i < PTC_NW; ++i) { weight[i] = 0.0f; emit[i] = 0.0f; }
 
         if (shading) {
             const uint32_t tri = hit.x;
-            // one batch of loads: all of them depend on (p, tri) only
-            const float4 ro = st.rays[2u * p], rd = st.rays[2u * p + 1u];
-            const uint2 state = st.state[p];
+            // one batch of loads: all of them depend on (pos, tri) only
+            const float4 ro = st.pray[cur][2u * (size_t)pos], rd = new_d;
+            const uint2 state = make_uint2(meta.y, meta.z);
             const float4* srec = sc.shade + (size_t)tri * 5u;
             const float4 t0 = sc.surf[tri];                                     // Intersection.normal = tri.n, material | flags
             uint32_t len = PTC_STATE_LEN(state.y), iter = PTC_STATE_ITER(state.y), emask = PTC_STATE_EMASK(state.y);
@@ -270,8 +285,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
                 put_vertex = true;
                 vslot = len;
                 len += 1u;
-                put_dir = survive;                                              // scene.rs:354-356
-                cont = survive;
+                cont = survive;                                                 // scene.rs:354-356 (new_d is the new direction)
             }
             iter += 1u;
             // loop header: `for _ in 0..1024` and the capacity check scene.rs:328-331
@@ -282,6 +296,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
         // hand the path on: ballot -> one LDS atomic per wave and list -> slot in the block's buffer
         const unsigned long long mmask = __ballot(missed), cmask = __ballot(cont), wmask = __ballot(cont && in_watched);
         const unsigned long long below = (1ull << lane) - 1ull;
+        uint32_t new_pos = 0u;
         if (cmask != 0ull) {
             const int leader = __ffsll((long long)cmask) - 1;
             uint32_t base = 0u;
@@ -290,7 +305,8 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
                 if (wmask != 0ull) atomicAdd(&q_n[2], (uint32_t)__popcll(wmask));
             }
             base = __shfl(base, leader);
-            if (cont) qbuf[base + (uint32_t)__popcll(cmask & below)] = p;
+            // the survivor's position in the other buffer: its rank among the span's survivors, from the span's first index
+            if (cont) { new_pos = span0 + base + (uint32_t)__popcll(cmask & below); qbuf[new_pos - span0] = new_pos; }
         }
         if (mmask != 0ull) {
             const int leader = __ffsll((long long)mmask) - 1;
@@ -300,13 +316,14 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
             if (missed) qbuf[PTC_SHADE_SPAN - 1u - (base + (uint32_t)__popcll(mmask & below))] = p;
         }
 
-        if (shading) {
-            if (put_vertex) store_vertex(st, p, vslot, weight, emit, has_emit);
-            if (cont) {
-                st.rays[2u * p] = new_o;
-                if (put_dir) st.rays[2u * p + 1u] = new_d;
-            }
-            st.state[p] = new_state;
+        if (put_vertex) store_vertex(st, p, vslot, weight, emit, has_emit);
+        if (cont) {
+            st.pray[cur ^ 1u][2u * (size_t)new_pos] = new_o;
+            st.pray[cur ^ 1u][2u * (size_t)new_pos + 1u] = new_d;
+            st.pmeta[cur ^ 1u][new_pos] = make_uint4(p, new_state.x, new_state.y, 0u);
+        } else if (active) {              // the path ends: here (k_accumulate wants its hero wavelength, new_d.w) or at the sky
+            st.tail[2u * (size_t)p] = new_d;
+            st.tail[2u * (size_t)p + 1u] = make_float4(__uint_as_float(new_state.y), 0.0f, 0.0f, 0.0f);
         }
     }
     // one global atomic per list and SPAN (a single counter word takes ~90 returning atomics per
@@ -328,9 +345,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky
     const uint32_t count = st.counts[6];
     for (uint32_t k = blockIdx.x * PTC_BLOCK + threadIdx.x; k < count; k += gridDim.x * PTC_BLOCK) {
         const uint32_t p = st.miss_queue[k];
-        const float4 rd = st.rays[2u * p + 1u];
-        const uint2 state = st.state[p];
-        const uint32_t len = PTC_STATE_LEN(state.y);
+        const float4 rd = st.tail[2u * (size_t)p];
+        const uint32_t sy = __float_as_uint(st.tail[2u * (size_t)p + 1u].x);
+        const uint32_t len = PTC_STATE_LEN(sy);
         float wl[PTC_NW], e[PTC_NW], zero[PTC_NW];
         ptc::wavelengths(rd.w, wl);
         float dx = rd.x, dy = rd.y, dz = rd.z;
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_sky(DevSceneView sc, const DevSky
 #pragma unroll
         for (int i = 0; i < PTC_NW; ++i) zero[i] = 0.0f;
         store_vertex(st, p, len, zero, e, true);
-        st.state[p] = make_uint2(state.x, (state.y + 1u) | (1u << (16u + len)));       // len + 1, emit bit of the sky vertex
+        st.tail[2u * (size_t)p + 1u].x = __uint_as_float((sy + 1u) | (1u << (16u + len)));     // len + 1, emit bit of the sky vertex
     }
 }
 
@@ -364,9 +381,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_accumulate(PassState st, uint32_t
     for (uint32_t blk = 0; blk * G < spp_pass; ++blk) {
         if (live) {
             const uint32_t p = slot * st.cap + blk * (st.npix * G) + pixel * G + g;
-            const uint32_t sy = st.state[p].y;
+            const uint32_t sy = __float_as_uint(st.tail[2u * (size_t)p + 1u].x);
             const uint32_t len = PTC_STATE_LEN(sy), emask = PTC_STATE_EMASK(sy);
-            const float hero = st.rays[2u * p + 1u].w;
+            const float hero = st.tail[2u * (size_t)p].w;
             float L[PTC_NW];
 #pragma unroll
             for (int i = 0; i < PTC_NW; ++i) L[i] = 0.0f;
@@ -461,7 +478,7 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
         slots = std::min<uint32_t>(ctx->tune_pass_slots, PTC_MAX_SLOTS);
         spp_pass = std::max(1u, spp_pass / slots);
     }
-    size_t o_acc, o_rays, o_hits, o_state, o_q0, o_q1, o_qm, o_cnt, o_verts;
+    size_t o_acc, o_ray0, o_ray1, o_meta0, o_meta1, o_hits, o_tail, o_q0, o_q1, o_qm, o_cnt, o_verts;
     for (;;) {
         const uint32_t n_pass = spp_count ? (spp_count + spp_pass - 1u) / spp_pass : 1u;
         slots = std::max(1u, std::min(slots, n_pass));
@@ -470,9 +487,11 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
         size_t off = 0;
         auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
         o_acc = carve((size_t)npix * sizeof(float4));
-        o_rays = carve(N * 2 * sizeof(float4));
-        o_hits = carve(N * sizeof(uint4));
-        o_state = carve(N * sizeof(uint2));
+        const size_t CAP = N + PTC_SHADE_SPAN;            // positions: a new pass starts on a span boundary behind the live paths
+        o_ray0 = carve(CAP * 2 * sizeof(float4)); o_ray1 = carve(CAP * 2 * sizeof(float4));
+        o_meta0 = carve(CAP * sizeof(uint4)); o_meta1 = carve(CAP * sizeof(uint4));
+        o_hits = carve(CAP * sizeof(uint4));
+        o_tail = carve(N * 2 * sizeof(float4));
         o_q0 = carve(N * 4); o_q1 = carve(N * 4); o_qm = carve(N * 4);
         o_cnt = carve(256);
         o_verts = carve(N * PTC_MAX_VERTS * 2 * PTC_NW * sizeof(float));
@@ -489,8 +508,9 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
     char* base = (char*)ctx->work;
     float4* acc = (float4*)(base + o_acc);
     PassState st{};
-    st.rays = (float4*)(base + o_rays); st.hits = (uint4*)(base + o_hits);
-    st.state = (uint2*)(base + o_state);
+    st.pray[0] = (float4*)(base + o_ray0); st.pray[1] = (float4*)(base + o_ray1);
+    st.pmeta[0] = (uint4*)(base + o_meta0); st.pmeta[1] = (uint4*)(base + o_meta1);
+    st.hits = (uint4*)(base + o_hits); st.tail = (float4*)(base + o_tail);
     st.queue[0] = (uint32_t*)(base + o_q0); st.queue[1] = (uint32_t*)(base + o_q1); st.miss_queue = (uint32_t*)(base + o_qm);
     st.counts = (uint32_t*)(base + o_cnt); st.verts = (float4*)(base + o_verts);
     st.npix = npix;
@@ -550,7 +570,7 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
         if (enq - harvested <= LOOKAHEAD) {
             rc = ptc_timed_event(ctx, 2 * n_timed);
             if (rc != PT_OK) return rc;
-            rc = ptc_launch_trace(ctx, scene, (const pt_ray*)st.rays, nullptr, st.queue[enq & 1u], &st.counts[2u * (enq % 3u)],
+            rc = ptc_launch_trace(ctx, scene, (const pt_ray*)st.pray[enq & 1u], nullptr, st.queue[enq & 1u], &st.counts[2u * (enq % 3u)],
                                   live_ub, (pt_hit*)st.hits);
             if (rc != PT_OK) return rc;
             rc = ptc_timed_event(ctx, 2 * n_timed + 1);
