@@ -364,7 +364,7 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
     }
 
     // ---- Triangle::new (triangle.rs:50-60) ---------------------------------------------------------
-    RawBuf<float4> tris((size_t)N * 3u), shade((size_t)N * 5u), surf(N), boxes(lbvh ? (size_t)N * 2u : 0u);   // every entry is written below
+    RawBuf<float4> tris((size_t)N * PTC_TRI_STRIDE), shade((size_t)N * 5u), boxes(lbvh ? (size_t)N * 2u : 0u);   // every entry is written below
     std::atomic<bool> bad_material{false};
     auto precompute = [&](uint32_t begin, uint32_t end) {
     for (uint32_t i = begin; i < end; ++i) {
@@ -390,17 +390,17 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
         cross3(n, ab, tmp);
         for (int k = 0; k < 3; ++k) n2[k] = tmp[k] / nn;
         const float d2 = -dot3(t.a, n2);
-        tris[(size_t)i * 3 + 0] = make_float4(n[0], n[1], n[2], dd);
-        tris[(size_t)i * 3 + 1] = make_float4(n1[0], n1[1], n1[2], d1);
-        tris[(size_t)i * 3 + 2] = make_float4(n2[0], n2[1], n2[2], d2);
+        tris[(size_t)i * PTC_TRI_STRIDE + 0] = make_float4(n[0], n[1], n[2], dd);
+        tris[(size_t)i * PTC_TRI_STRIDE + 1] = make_float4(n1[0], n1[1], n1[2], d1);
+        tris[(size_t)i * PTC_TRI_STRIDE + 2] = make_float4(n2[0], n2[1], n2[2], d2);
         float mw, fw;
         const uint32_t flags = t.flags & (PT_TRI_HAS_UV | PT_TRI_HAS_NORMALS);
         std::memcpy(&mw, &t.material_index, 4); std::memcpy(&fw, &flags, 4);
-        // what every scatter needs, in one 16-byte record: Intersection.normal (= n) and material | flags
+        // what every scatter needs, in the fourth quarter of the record: Intersection.normal (= n) and material | flags
         const uint32_t mf = (t.material_index << 2) | flags;
         float mfw;
         std::memcpy(&mfw, &mf, 4);
-        surf[i] = make_float4(n[0], n[1], n[2], mfw);
+        tris[(size_t)i * PTC_TRI_STRIDE + 3] = make_float4(n[0], n[1], n[2], mfw);
         float4* s = &shade[(size_t)i * 5];
         s[0] = make_float4(mw, fw, t.uv[0][0], t.uv[0][1]);
         s[1] = make_float4(t.uv[1][0], t.uv[1][1], t.uv[2][0], t.uv[2][1]);
@@ -484,7 +484,6 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
         (rc = upload(ctx, s, wide, &s->view.wide, "wide nodes")) != PT_OK ||
         (rc = upload(ctx, s, tris, &s->view.tris, "triangles")) != PT_OK ||
         (rc = upload(ctx, s, shade, &s->view.shade, "shading records")) != PT_OK ||
-        (rc = upload(ctx, s, surf, &s->view.surf, "surface records")) != PT_OK ||
         (rc = upload(ctx, s, mats, &s->view.materials, "materials")) != PT_OK ||
         (rc = upload(ctx, s, images, &s->view.images, "images")) != PT_OK ||
         (rc = upload(ctx, s, texels, &s->view.texels, "texels")) != PT_OK ||

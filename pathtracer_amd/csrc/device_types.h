@@ -32,9 +32,10 @@
 //   w0..w2 = min.x, min.y, min.z of slots 0..3   w3..w5 = max.x, max.y, max.z of slots 0..3
 //   w6 = bits(ref 0..3): leaf bit | triangle, or wide-node index
 //   w7 = unused (keeps the stride one cache line)
-// ---- triangle intersect record: 48 B = 3 x float4 (triangle.rs:17-24)
-//   t0 = { n.xyz, d }   t1 = { n1.xyz, d1 }   t2 = { n2.xyz, d2 }
-// ---- surface record: 16 B {n.xyz, bits(material << 2 | flags)}: the one gather per scatter of a triangle without uv/normals
+// ---- triangle record: 64 B = 4 x float4, so that no record straddles two 128-byte lines (a 48-byte record does in one fetch of four)
+//   t0 = { n.xyz, d }   t1 = { n1.xyz, d1 }   t2 = { n2.xyz, d2 }      the intersect part (triangle.rs:17-24), read by the leaf test
+//   t3 = { n.xyz, bits(material << 2 | flags) }                         the one gather per scatter of a triangle without uv/normals
+#define PTC_TRI_STRIDE 4u   /* float4 per triangle record */
 // ---- triangle shading record: 80 B = 5 x float4; the common (no uv, no normals) case reads s0 only
 //   s0 = { bits(material), bits(flags), uv0.x, uv0.y }
 //   s1 = { uv1.x, uv1.y, uv2.x, uv2.y }
@@ -59,9 +60,8 @@ struct DevSky {
 struct DevSceneView {       // passed to kernels by value
     const float4* nodes;
     const float4* wide;         // [n_wide][8], see above
-    const float4* tris;
+    const float4* tris;         // [n_tris][PTC_TRI_STRIDE]
     const float4* shade;
-    const float4* surf;         // [n_tris] { n.x, n.y, n.z, bits(material << 2 | flags) }: all a flat-shaded scatter reads
     const DevMaterial* materials;
     const DevImage* images;
     const float* texels;

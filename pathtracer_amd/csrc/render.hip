@@ -203,7 +203,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
             const float4 ro = st.pray[cur][2u * (size_t)pos], rd = new_d;
             const uint2 state = make_uint2(meta.y, meta.z);
             const float4* srec = sc.shade + (size_t)tri * 5u;
-            const float4 t0 = sc.surf[tri];                                     // Intersection.normal = tri.n, material | flags
+            const float4 t0 = sc.tris[(size_t)tri * PTC_TRI_STRIDE + 3u];                                     // Intersection.normal = tri.n, material | flags
             uint32_t len = PTC_STATE_LEN(state.y), iter = PTC_STATE_ITER(state.y), emask = PTC_STATE_EMASK(state.y);
             float wl[PTC_NW];
             ptc::wavelengths(rd.w, wl);

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_mint_persistent(
             if ((cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
                 const uint32_t tri = cur & PTC_INDEX_MASK;
                 if (tri != skip) {
-                    const float4* tp = sc.tris + (size_t)tri * 3u;
+                    const float4* tp = sc.tris + (size_t)tri * PTC_TRI_STRIDE;
                     float d, u, v;
                     if (ptc_tri_test(r, tp[0], tp[1], tp[2], d, u, v) && d <= best_t) {
                         best_t = d; best_u = u; best_v = v; best_id = tri;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
             if (has_ray && (cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
                 const uint32_t tri = cur & PTC_INDEX_MASK;
                 if (tri != skip) {
-                    const float4* tp = sc.tris + (size_t)tri * 3u;
+                    const float4* tp = sc.tris + (size_t)tri * PTC_TRI_STRIDE;
                     float d, u, v;
                     if (ptc_tri_test(r, tp[0], tp[1], tp[2], d, u, v)) {
                         if (!(pt_fabs(d) < pt_inf())) {          // Some(inf) / Some(NaN): only the frames get those right
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_replay_persistent(
                 const uint32_t tri = cur & PTC_INDEX_MASK;
                 ret_id = PTC_NONE_ID; ret_t = pt_inf();
                 if (tri != skip) {
-                    const float4* tp = sc.tris + (size_t)tri * 3u;
+                    const float4* tp = sc.tris + (size_t)tri * PTC_TRI_STRIDE;
                     float d, u, v;
                     if (ptc_tri_test(r, tp[0], tp[1], tp[2], d, u, v)) { ret_id = tri; ret_t = d; }
                 }
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_replay_persistent(
                     uint4 o = make_uint4(PT_NO_TRIANGLE, 0u, 0u, 0u);
                     if (ret_id != PTC_NONE_ID) {
                         // u, v of the winner: the same arithmetic on the same inputs gives the same bits
-                        const float4* tp = sc.tris + (size_t)ret_id * 3u;
+                        const float4* tp = sc.tris + (size_t)ret_id * PTC_TRI_STRIDE;
                         float d, u, v;
                         ptc_tri_test(r, tp[0], tp[1], tp[2], d, u, v);
                         o = make_uint4(ret_id, __float_as_uint(d), __float_as_uint(u), __float_as_uint(v));
