@@ -185,7 +185,7 @@ void pt_scene_file_free(pt_scene_file* file);
 
 /* ---- seam 1: scene upload (replaces holding Scene{bvh,triangles,materials,sky}, scene.rs:273-281)
  * Copies the caller's arrays, flattens nodes to the 64-byte device layout and triangles to the
- * 48-byte intersect record + shading record, and owns the device memory until destroy. */
+ * 64-byte triangle record (intersect part + normal and material) + shading record, and owns the device memory until destroy. */
 int  pt_scene_create(pt_ctx* ctx, const pt_scene_desc* desc, pt_scene** out);
 /* Same, with the BVH built ON THE GPU instead of taken from the caller (no counterpart
  * in the reference, whose BVH::build is a host recursion): desc->nodes must be NULL.  LBVH — 63-bit Morton
