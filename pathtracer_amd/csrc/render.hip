@@ -189,13 +189,9 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
         const bool missed = active && hit.x == PT_NO_TRIANGLE;
         const bool shading = active && !missed;
 
-        bool cont = false, put_vertex = false, has_emit = false, in_watched = false;
-        float weight[PTC_NW], emit[PTC_NW];
+        bool cont = false, in_watched = false;
         float4 new_o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         uint2 new_state = make_uint2(meta.y, meta.z);
-        uint32_t vslot = 0u;
-#pragma unroll
-        for (int i = 0; i < PTC_NW; ++i) { weight[i] = 0.0f; emit[i] = 0.0f; }
 
         if (shading) {
             const uint32_t tri = hit.x;
@@ -247,6 +243,11 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
                 float sph[3];
                 pt_rng_unit_sphere(&rng, sph);                                  // material.rs:168
                 new_d = make_float4(nx + sph[0], ny + sph[1], nz + sph[2], rd.w);
+                // the vertex is stored HERE, not after the queue hand-off below: its 16 registers are dead before the ballots
+                bool has_emit = false;
+                float weight[PTC_NW], emit[PTC_NW];
+#pragma unroll
+                for (int i = 0; i < PTC_NW; ++i) emit[i] = 0.0f;
                 float cr, cg, cb;
                 ptc::texture_rgb(sc, m.diffuse_img, m.diffuse, u, v, cr, cg, cb);
                 // The empty asm makes wavelength i+1 "depend" on the result of wavelength i-1: without it the
@@ -282,8 +283,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
                         for (int i = 0; i < PTC_NW; ++i) weight[i] = 0.0f;
                     }
                 }
-                put_vertex = true;
-                vslot = len;
+                store_vertex(st, p, len, weight, emit, has_emit);
                 len += 1u;
                 cont = survive;                                                 // scene.rs:354-356 (new_d is the new direction)
             }
@@ -316,7 +316,6 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
             if (missed) qbuf[PTC_SHADE_SPAN - 1u - (base + (uint32_t)__popcll(mmask & below))] = p;
         }
 
-        if (put_vertex) store_vertex(st, p, vslot, weight, emit, has_emit);
         if (cont) {
             st.pray[cur ^ 1u][2u * (size_t)new_pos] = new_o;
             st.pray[cur ^ 1u][2u * (size_t)new_pos + 1u] = new_d;
