@@ -176,7 +176,7 @@ def main():
 
         if use_dist:   # warm the communicator on a buffer of this size
             dist.all_reduce(torch.zeros_like(d_img))
-        # warm-up: one pass-sized call, so that the pass workspace (about 1.1 KiB per path in flight) is allocated before
+        # warm-up: one pass-sized call, so that the pass workspace (about 1.15 KiB per path in flight) is allocated before
         # the timed region
         ctx.render_dev(scene, width, height, begin, min(count, max(1, (128 << 20) // (width * height))), spp_total, 1, mode, d_img.data_ptr())
         sharding.finalize_sums(d_img.clone())       # first use of these torch kernels loads their code objects

@@ -14,12 +14,13 @@
 // appended to the same queue, so that a traversal launch never holds only the thin tail of one pass (the last ten of
 // a pass's ~18 iterations hold < 3 % of its paths and cost a ray's latency each).  A pass is folded into the image
 // when the host learns that its last path has ended, oldest pass first, so every pixel still receives its samples in
-// sample order.  Per-path state lives in HBM indexed by the path id, packed so that
-// every access is a whole 8/16/64-byte record (after a few bounces the live paths are sparse in p,
-// and 4-byte columns would touch one cache line per value); QUEUES hold the ids of live paths.  Each iteration the traversal kernel (trace.hip)
-// extends every queued ray, then the shade kernel consumes the hits, pushes one {weight, emit}
-// vertex per scatter into the path's vertex column and appends surviving paths to the next queue
-// with a wave-level ballot/prefix compaction (one atomic per wave).
+// sample order.  The state of a LIVE path (ray, rng index, state word, hit) lives at a POSITION, not at the path id: every
+// k_shade writes the survivors of a span of the queue side by side into the other of two buffers, so that after any number
+// of bounces the live paths are dense in memory (PassState below); the QUEUES hold positions.  Only what a path leaves
+// behind - its vertices, and 32 bytes when it ends - is indexed by the path id; every access is a whole 16/32/64-byte
+// record.  Each iteration the traversal kernel (trace.hip) extends every queued ray, then the shade kernel consumes the
+// hits, writes one {weight, emit} vertex per scatter into the path's vertex column and appends the surviving paths to the
+// next queue (ballot / popcount ranks into a per-block LDS list, one global atomic per list and 2 048 paths).
 //
 // The vertex column stores the sub-path exactly as the reference's ArrayVec<Bounce, 16> does, so
 // the accumulate kernel can fold it back to front, L = L*w + e (scene.rs:371-373), in the
@@ -465,7 +466,7 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
     PTC_HIP(ctx, hipSetDevice(ctx->device));
     ctx->stats = pt_stats{};
 
-    // ctx->tune_pass_paths paths in flight (1.1 KiB of HBM each).  A render that fits is ONE pass; a longer one is cut
+    // ctx->tune_pass_paths paths in flight (1.15 KiB of HBM each).  A render that fits is ONE pass; a longer one is cut
     // into passes of whole samples, ctx->tune_pass_slots of them in flight, each 1 / slots of the budget.  When the
     // workspace does not fit in what is left of HBM the pass is halved until it does (one sample of every pixel is the
     // floor, then fewer slots): that costs throughput, never the image (samples are independent and each pixel adds its
