@@ -155,14 +155,14 @@ __global__ void k_admit(uint32_t* counts, uint32_t c, uint32_t n, uint32_t watch
 // the grid is sized for an upper bound and surplus threads only take part in the ballots.
 //
 // Everything that depends only on the hit (ray, state, shading record, triangle normal) is requested in
-// one batch, the spectral tables live in LDS, and the ids of paths that go on (to the next iteration's
-// queue, or to the miss queue) are collected per block in LDS and appended with ONE global atomic per
-// list and span of PTC_SHADE_SPAN paths.
+// one batch, the spectral tables live in LDS, and the paths that go on (their new positions to the next
+// iteration's queue, the ids of those that missed to the miss queue) are collected per block in LDS and
+// appended with ONE global atomic per list and span of PTC_SHADE_SPAN paths.
 __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState st, uint32_t cur, uint32_t cin,
                                                     uint64_t seed, uint32_t watch_slot) {
     __shared__ ptc::SpectralLds tab;
-    // ids of the paths this block sends on: survivors fill qbuf from the front, misses from the back
-    // (they are disjoint subsets of the PTC_SHADE_SPAN paths a block handles per span)
+    // what this block sends on: the survivors' new POSITIONS fill qbuf from the front, the ids of the paths that missed
+    // from the back (they are disjoint subsets of the PTC_SHADE_SPAN paths a block handles per span)
     __shared__ uint32_t qbuf[PTC_SHADE_SPAN];
     __shared__ uint32_t q_n[3], q_base[2];              // continuing, missed, continuing in the watched slot
     const uint32_t count = st.counts[2u * cin];
