@@ -307,7 +307,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_trace_mint_persistent(
 template <int S, bool QUEUED>
 // (waves_per_eu 4..5: with the default target the register allocator spills the ray's inverse direction to scratch and
 // reloads it at every record, and with a target of six waves it still spills 16 bytes per lane - scratch stores reach HBM;
-// at five the kernel takes 80 VGPRs and no scratch, the descriptor admits five blocks per CU and the launcher asks for five)
+// at five the kernel takes 76 VGPRs and no scratch, the descriptor admits five blocks per CU and the launcher asks for five)
 __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_trace_scoped_persistent(
     DevSceneView sc, const float4* __restrict__ rays, const uint32_t* __restrict__ start,
     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count_ptr, uint32_t n,
@@ -332,7 +332,9 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
     RayTickets tk;
     tk.init(n);
     bool has_ray = false;
-    DRay r = {};
+    // the ray as nine scalars (a DRay is made of them where the step functions want one): as a struct its inverse direction
+    // stayed in memory, and LLVM moved that to LDS (3 KB per block, a read per record)
+    float rox = 0.0f, roy = 0.0f, roz = 0.0f, rdx = 0.0f, rdy = 0.0f, rdz = 0.0f, rix = 0.0f, riy = 0.0f, riz = 0.0f;
     uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE;
     float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
     float m_cur = pt_inf();          // minimum t found since the newest stack entry was pushed (inf: none)
@@ -348,11 +350,12 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
             if (tk.take(idle, n_idle, lane, !has_ray, n, ticket, ticket_size, k)) {
                 ray_i = QUEUED ? queue[k] : k;
                 const float4 ro = rays[2 * (size_t)ray_i];
-                r = ptc_make_ray(ro, rays[2 * (size_t)ray_i + 1]);
+                const DRay r = ptc_make_ray(ro, rays[2 * (size_t)ray_i + 1]);
                 skip = QUEUED ? __float_as_uint(ro.w) : (start ? start[ray_i] : PT_NO_TRIANGLE);
                 if (ptc_ray_is_regular(r)) {
                     best_t = pt_inf(); best_u = 0.0f; best_v = 0.0f; best_id = PT_NO_TRIANGLE;
                     m_cur = pt_inf();
+                    rox = r.ox; roy = r.oy; roz = r.oz; rdx = r.dx; rdy = r.dy; rdz = r.dz; rix = r.ix; riy = r.iy; riz = r.iz;
                     sign_ok = ptc_ray_sign_select(r);
                     near_x = r.ix < 0.0f ? 48u : 0u; near_y = r.iy < 0.0f ? 64u : 16u; near_z = r.iz < 0.0f ? 80u : 32u;
                     st.reset();
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
             // ---- phase 1: wide record = bvh.rs:259-325 at a binary node and at the child it enters ----
             {
                 PtcWideStep s;
+                const DRay r = {rox, roy, roz, rdx, rdy, rdz, rix, riy, riz};
                 // Sign-select form (trace_step.h) when every ray of the wave has a finite, non-zero inverse direction and the
                 // scene allows it: each lane loads the near planes (lo or hi by the sign of its inverse direction) and the far
                 // planes, and the 24 min / max that pick them drop out.  Uniform base + 32-bit lane offset addressing.
@@ -412,6 +416,7 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                 if (tri != skip) {
                     const float4* tp = sc.tris + (size_t)tri * PTC_TRI_STRIDE;
                     float d, u, v;
+                    const DRay r = {rox, roy, roz, rdx, rdy, rdz, rix, riy, riz};
                     if (ptc_tri_test(r, tp[0], tp[1], tp[2], d, u, v)) {
                         if (!(pt_fabs(d) < pt_inf())) {          // Some(inf) / Some(NaN): only the frames get those right
                             redo_list[atomicAdd(redo_count, 1u)] = ray_i;
