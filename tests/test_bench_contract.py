@@ -1,5 +1,5 @@
 """The JSON line bench.py prints (driver contract): checked on the committed output of the last GPU run
-(profiles/r02j_bench.json is what `python bench.py` printed on the MI355X box) and on bench.py's own source."""
+(profiles/r02k_bench.json is what `python bench.py` printed on the MI355X box) and on bench.py's own source."""
 import json
 import os
 import re
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_every_contract_key():
-    j = json.load(open(os.path.join(ROOT, "profiles", "r02j_bench.json")))
+    j = json.load(open(os.path.join(ROOT, "profiles", "r02k_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
@@ -30,7 +30,7 @@ def test_committed_bench_line_has_every_contract_key():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     assert t["traversal"] == "exact" and t["rays"] == j["config"]["rays_per_step_per_gpu"] and t["kernel"].startswith("k_trace_scoped_persistent")
     assert r["traffic"] == t["hbm_bytes_per_launch"]
-    summary = open(os.path.join(ROOT, "profiles", "r02j_summary.txt")).read()
+    summary = open(os.path.join(ROOT, "profiles", "r02k_summary.txt")).read()
     assert "k_trace_scoped_persistent" in summary and "SQ_INSTS_VALU" in summary and "TCP_TOTAL_CACHE_ACCESSES_sum" in summary
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "host_cpus_visible"):
