@@ -50,6 +50,67 @@ def host_threads():
     return max(1, min(avail, 16))
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launcher_command(argv, gpus, port):
+    """The command `python bench.py --gpus N` (N > 1, no RANK in the environment) starts as a CHILD: one rank per GPU under
+    torch.distributed.run, the same arguments handed through."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(a, argv):
+    """Called before torch is imported and before anything touches the GPU.  Starts the ranks as a child process (never an
+    exec), relays rank 0's JSON line and everything else the ranks print, returns the child's exit status."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "16")
+    cmd = launcher_command(argv, a.gpus, free_port())
+    print("bench.py: starting %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    seen_json = False
+    for line in child.stdout:              # relayed as it arrives: a long run keeps printing
+        if line.lstrip().startswith("{") and ('"metric"' in line or '"launch_check"' in line):
+            seen_json = True
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = child.wait()
+    if rc == 0 and not seen_json:
+        print("bench.py: the ranks ended without a JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def launch_check(a):
+    """--launch-check: the rendezvous of the N ranks and nothing else (no GPU call when the backend is gloo): an all-reduce of
+    ones proves how many ranks the process group holds.  What tests/test_bench_contract.py runs on the CPU."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if a.backend == "nccl":
+        local_rank = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        ones = torch.ones(1, device="cuda")
+    else:
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
+        ones = torch.ones(1)
+    dist.all_reduce(ones)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": a.gpus, "world_size": world, "ranks_seen": int(ones.item()),
+                          "backend": dist.get_backend()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,7 +126,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --one-device rehearses the N>1 code path on a 1-GPU box")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, count them with one all-reduce, print that and stop (no benchmark)")
     a = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 starts its own ranks: a child `python -m torch.distributed.run` BEFORE torch is
+    # imported or the GPU touched in this process (under torch.distributed.run RANK is set and this is a rank already)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(a, sys.argv[1:]))
+    if a.launch_check:
+        return launch_check(a)
 
     import torch
     import torch.distributed as dist
@@ -75,8 +144,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE is {world}: one rank per GPU")
     if a.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -90,6 +158,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
+
+    # how many ranks the process group really holds: an all-reduce of ones over the backend the legs below use
+    ranks_seen = 1
+    if use_dist:
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
     def barrier():
         if use_dist:
@@ -231,10 +306,11 @@ def main():
         except Exception as e:
             config4 = {"metric": "spectral spp/s at 3840x2160, 1M tris, sample-split", "value": None, "unit": "spp/s", "error": f"{type(e).__name__}: {e}"}
 
-    # ---- CPU baseline + visit counts (rank 0, N = 1 only: bounded, about 10-30 s of CPU work) -------
+    # ---- CPU baseline + visit counts (rank 0 only, also at N > 1: bounded, about 10-30 s of CPU work on rank 0's own
+    # rays while the other ranks wait at the last barrier) -------
     cpu_baseline, n_node, n_tri, counts_src = None, None, None, None
     golden = os.path.join(ROOT, "tests", "golden", "soup1m_primary_counts.json")
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and not a.no_cpu_baseline:
         try:
             from tests.oracle import Oracle
             o = Oracle()
@@ -257,7 +333,7 @@ def main():
             }
             if spectral is not None and spectral.get("value") is not None:
                 # spectral leg beside it: sample 0 of every pixel (1 of the 64 spp: ~2 M paths, ~8 M segments)
-                spp_total = a.spectral_spp
+                spp_total = a.spectral_spp * world
                 t1 = time.perf_counter()
                 cpu_img, ccnt = o.render(osc, a.width, a.height, 0, 1, spp_total, 1, mode=abi.PT_RENDER_SUM, count=True)
                 cpu_s = time.perf_counter() - t1
@@ -276,7 +352,7 @@ def main():
                 # sample (every sample of a pixel is statistically the same work)
                 paths, segs, nodes, tris_t = ccnt
                 per_path = (segs * (32 + 16 + 2 * 128 + 64 + 48) + 64 * nodes + 48 * tris_t) / paths + 16
-                total = per_path * a.width * a.height * a.spectral_spp
+                total = per_path * a.width * a.height * spp_total
                 gbps = total / spectral["seconds"] / 1e9
                 # counter bytes of the integrator's kernels (tools/pmc_integrator.sh on this scene and frame), per path-sample
                 it, itp = {}, os.path.join(ROOT, "profiles", "integrator_traffic.json")
@@ -284,7 +360,7 @@ def main():
                     it = json.load(open(itp))
                     if not (it.get("tris") == a.tris and it.get("width") == a.width and it.get("height") == a.height and it.get("traversal") == a.traversal):
                         it = {}
-                traffic = it["bytes_per_path_sample"] * a.width * a.height * a.spectral_spp if it else None
+                traffic = it["bytes_per_path_sample"] * a.width * a.height * spp_total if it else None
                 spectral["roofline"] = {
                     "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": traffic,
                     "hbm_counter_frac": (traffic / spectral["seconds"] / 8e12) if traffic else None,
@@ -362,6 +438,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "closest-hit Mrays/s", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
+            "ranks_seen": ranks_seen, "backend": (dist.get_backend() if use_dist else None),
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {

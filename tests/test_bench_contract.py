@@ -60,3 +60,38 @@ def test_bench_reads_nothing_from_the_reference_at_run_time():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "/root/reference" not in src
     assert re.search(r"--gpus", src) and re.search(r"--steps", src) and re.search(r"--warmup", src)
+
+
+def test_bench_starts_its_own_ranks_and_counts_them():
+    """`python bench.py --gpus 2` - the plain command, no torchrun - starts two ranks as a child process before anything touches
+    the GPU; --launch-check stops after the rendezvous (gloo here: no GPU), and the line says how many ranks the group holds."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j == {"launch_check": True, "n_gpus": 2, "world_size": 2, "ranks_seen": 2, "backend": "gloo"}
+    assert "torch.distributed.run" in p.stderr and "--nproc-per-node=2" in p.stderr
+
+
+def test_launcher_command_is_a_child_torchrun_and_never_an_exec():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    cmd = b.launcher_command(["--gpus", "8", "--steps", "3"], 8, 12345)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src
+    # the launch happens before torch is imported in the launcher process
+    main_src = src[src.index("def main():"):]
+    assert main_src.index("self_launch(a") < main_src.index("import torch")
+    # the line carries the rank count and keeps the CPU baseline at N > 1
+    assert '"ranks_seen": ranks_seen' in src and "if rank == 0 and not a.no_cpu_baseline" in src

@@ -93,6 +93,34 @@ def test_ptrender_mgpu_single_rank_equals_ptrender(tmp_path):
         assert r.returncode == 1 and "one rank per GPU" in r.stderr
 
 
+@pytest.mark.gpu
+def test_ptrender_mgpu_soup_workload_equals_the_python_harness(gpu_ctx, tmp_path):
+    """configs 3 / 4 from the compiled host: `--soup N --sky hw --size WxH` builds the same soup (generator, materials, sky) as
+    pathtracer_amd/workloads.py, so its image must be the Python harness's bit for bit; a scene that cannot be loaded ends
+    the ranks by agreement (exit 1, message), not by a signal."""
+    import json
+    import numpy as np
+    from pathtracer_amd import workloads
+    root = os.path.dirname(HERE)
+    exe = os.path.join(root, "harness", "ptrender_mgpu")
+    out = str(tmp_path / "soup")
+    q = subprocess.run([exe, "--soup", "20000", out, "--gpus", "1", "--spp", "3", "--seed", "4", "--size", "320x180", "--sky", "hw"],
+                       capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stdout + q.stderr
+    line = json.loads(q.stdout.strip().splitlines()[-1])
+    assert line["ranks_seen"] == 1 and line["width"] == 320 and line["height"] == 180 and line["spp"] == 3 and "soup-20000" in line["workload"]
+    raw = open(out + ".pfm", "rb").read()
+    head = b"PF\n320 180\n-1.0\n"
+    assert raw.startswith(head)
+    pfm = np.frombuffer(raw[len(head):], dtype="<f4").reshape(180, 320, 3)[::-1]
+    arr = workloads.soup_scene(20000, sky=workloads.hw_sky())
+    img = gpu_ctx.render(gpu_ctx.scene(arr), 320, 180, 0, 3, 3, seed=4)
+    got, want = pfm, img[..., :3]
+    assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all()
+    bad = subprocess.run([exe, str(tmp_path / "absent.toml"), out, "--gpus", "1"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "could not load the scene" in bad.stderr
+
+
 def test_ptrender_mgpu_usage():
     root = os.path.dirname(HERE)
     exe = os.path.join(root, "harness", "ptrender_mgpu")
