@@ -233,7 +233,11 @@ int pt_trace_closest_dev_noalloc(pt_ctx* ctx, const pt_scene* scene, const pt_ra
  *          leaves are visited in the same order under the same local rule (the far child is entered iff the near child's
  *          own result is farther than the far box, bvh.rs:285; the later visit wins an equal-t tie, bvh.rs:299-303), two
  *          tree levels per memory fetch.  Rays with a non-finite component, and rays that meet a triangle at a non-finite
- *          distance, are traced by REPLAY inside the same call.
+ *          distance, are traced by REPLAY inside the same call.  The kernel does not read the two child boxes stored in a
+ *          node at odd depth: it re-derives each from that child's own two child boxes (their minNum / maxNum join, which is
+ *          what BVH::build and PT_SCENE_BUILD_LBVH store).  pt_scene_create checks a caller's node vector for this; a tree
+ *          whose stored boxes are looser (refitted, padded) is traversed by REPLAY, which reads the stored boxes, whenever
+ *          EXACT is asked for - same answer as traverse_recursive on THAT tree, at REPLAY's rate.
  *   REPLAY the recursion frame by frame over the binary nodes; same results as EXACT, about half its rate.
  *   MIN_T  prunes against the best hit of the whole ray instead: returns a hit of minimum t, fastest; WHICH triangle of an
  *          exact equal-t tie - or of two hits an ulp or two apart where a box's entry distance rounds above the t of its own

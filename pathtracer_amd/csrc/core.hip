@@ -111,6 +111,7 @@ static int pt_init_body(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_shade_blocks_per_cu = std::max(1u, env_u32("PTC_SHADE_BLOCKS_PER_CU", ctx->tune_shade_blocks_per_cu));
     ctx->tune_ring = env_u32("PTC_RING", ctx->tune_ring);
     ctx->tune_flatten = std::min(2u, env_u32("PTC_FLATTEN", ctx->tune_flatten));
+    ctx->tune_trust_joins = env_u32("PTC_TRUST_JOINS", 0u) != 0u;
     ctx->tune_host_chunk = std::max(1u << 12, std::min(1u << 28, env_u32("PTC_HOST_CHUNK", ctx->tune_host_chunk)));
     ctx->tune_pass_paths = std::max(1u << 16, std::min(192u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
     ctx->tune_work_limit = (size_t)env_u32("PTC_WORK_LIMIT_MB", 0u) << 20;
@@ -308,8 +309,10 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
             float4* q = &nodes[(size_t)internal_rank[i] * 4u];
             float lw, rw;
             std::memcpy(&lw, &lref, 4); std::memcpy(&rw, &rref, 4);
-            for (int k = 0; k < 3; ++k)         // an inverted box (never made by BVH::build) rules out the sign-select wide step
-                if (nd.child_l_aabb.min[k] > nd.child_l_aabb.max[k] || nd.child_r_aabb.min[k] > nd.child_r_aabb.max[k]) boxes_ordered = false;
+            for (int k = 0; k < 3; ++k) {       // an inverted box, or one with a NaN on one side only (never made by BVH::build), rules out the sign-select wide step
+                const float a = nd.child_l_aabb.min[k], b = nd.child_l_aabb.max[k], c = nd.child_r_aabb.min[k], e = nd.child_r_aabb.max[k];
+                if (!(a <= b || (a != a && b != b)) || !(c <= e || (c != c && e != e))) boxes_ordered = false;
+            }
             q[0] = make_float4(nd.child_l_aabb.min[0], nd.child_l_aabb.min[1], nd.child_l_aabb.min[2], lw);
             q[1] = make_float4(nd.child_l_aabb.max[0], nd.child_l_aabb.max[1], nd.child_l_aabb.max[2], rw);
             q[2] = make_float4(nd.child_r_aabb.min[0], nd.child_r_aabb.min[1], nd.child_r_aabb.min[2], 0.0f);
@@ -323,6 +326,7 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
     // 1 = this host-side loop instead, 2 = both, and the two arrays must be byte-identical (consistency check for tests).
     std::vector<float4> wide;
     uint32_t wide_depth = 0;
+    bool joins_exact = true;        // see DevSceneView::joins_exact (k_check_joins in lbvh.hip is the device's form of the loop below)
     const uint32_t wide_mode = lbvh ? 0u : ctx->tune_wide_collapse;
     if (n_internal && wide_mode != 0u) {
         // wide nodes = internal nodes at odd depth, numbered in node (pre)order; slots = the grandchildren at fixed
@@ -350,7 +354,16 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
                 const int base = side ? 0 : 2;
                 uint32_t ref; std::memcpy(&ref, side ? &q[1].w : &q[0].w, 4);
                 if (ref & PTC_LEAF_BIT) take(q, side, base);
-                else { const float4* q2 = &nodes[(size_t)ref * 4u]; take(q2, 1, base); take(q2, 0, base + 1); }
+                else {
+                    const float4* q2 = &nodes[(size_t)ref * 4u];
+                    take(q2, 1, base); take(q2, 0, base + 1);
+                    const float4 slo = q[side ? 2 : 0], shi = q[side ? 3 : 1];
+                    const float sl[3] = {slo.x, slo.y, slo.z}, sh[3] = {shi.x, shi.y, shi.z};
+                    const float jl[3] = {pt_fmin(q2[0].x, q2[2].x), pt_fmin(q2[0].y, q2[2].y), pt_fmin(q2[0].z, q2[2].z)};
+                    const float jh[3] = {pt_fmax(q2[1].x, q2[3].x), pt_fmax(q2[1].y, q2[3].y), pt_fmax(q2[1].z, q2[3].z)};
+                    for (int k = 0; k < 3; ++k)
+                        if (!(sl[k] == jl[k] || (sl[k] != sl[k] && jl[k] != jl[k])) || !(sh[k] == jh[k] || (sh[k] != sh[k] && jh[k] != jh[k]))) joins_exact = false;
+                }
             }
             float4* w = &wide[(size_t)wide_index[r] * 8u];
             for (int a = 0; a < 3; ++a) {
@@ -519,11 +532,13 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
     if (!lbvh && n_internal && wide_mode != 1u) {
         float4* d_wide = nullptr;
         uint32_t n_wide = 0, dev_depth = 0, dev_wide_depth = 0;
-        rc = ptc_build_wide_from_nodes(ctx, s->view.nodes, n_internal, &d_wide, &n_wide, &dev_depth, &dev_wide_depth);
+        bool dev_joins = true;
+        rc = ptc_build_wide_from_nodes(ctx, s->view.nodes, n_internal, &d_wide, &n_wide, &dev_depth, &dev_wide_depth, &dev_joins);
         if (rc != PT_OK) { pt_scene_destroy(ctx, sc.release()); return rc; }
         s->allocations.push_back(d_wide);
         if (!host_flatten) max_depth = dev_depth;
-        bool same = dev_depth == max_depth;
+        bool same = dev_depth == max_depth && (wide_mode != 2u || dev_joins == joins_exact);
+        joins_exact = dev_joins;
         if (wide_mode == 2u) {
             std::vector<float4> back((size_t)n_wide * 8u);
             same = same && back.size() == wide.size() && dev_wide_depth == wide_depth &&
@@ -553,6 +568,7 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
     s->view.max_depth = max_depth;
     s->view.wide_depth = wide_depth;
     s->view.sign_select_ok = (boxes_ordered && (uint64_t)n_internal * 128u < (1ull << 32)) ? 1u : 0u;      // (n_wide <= n_internal)
+    s->view.joins_exact = (joins_exact || ctx->tune_trust_joins) ? 1u : 0u;
     s->view.root_ref = (N == 1) ? (PTC_LEAF_BIT | (lbvh ? 0u : d->nodes[0].shape_index)) : 0u;
     s->info.n_triangles = N;
     s->info.n_internal_nodes = n_internal;

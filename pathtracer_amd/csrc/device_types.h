@@ -76,6 +76,10 @@ struct DevSceneView {       // passed to kernels by value
     uint32_t max_depth;
     uint32_t sign_select_ok;    // every box has min <= max (or is NaN) and the wide array is below 4 GiB: the EXACT kernel may
                                 // load near / far planes by the sign of the ray's inverse direction (trace_step.h)
+    uint32_t joins_exact;       // every child box the EXACT kernel re-derives (the two children of an odd-depth node) IS the minNum /
+                                // maxNum join of that child's own two child boxes, as in every tree BVH::build or the LBVH makes.  A
+                                // caller's refitted / padded tree need not be: EXACT calls on such a scene run the frame-replay kernel,
+                                // which reads the stored boxes (same answer as traverse_recursive on that tree)
 };
 
 struct pt_scene {
@@ -113,6 +117,7 @@ struct pt_ctx {
     uint32_t tune_refill = 16;
     uint32_t tune_wide_collapse = 0;     // wide records of caller-supplied trees: 0 on the device, 1 on the host, 2 both + compare
     uint32_t tune_flatten = 0;           // caller-supplied node vectors are validated and flattened: 0 on the device, 1 on the host, 2 both + compare
+    bool     tune_trust_joins = false;   // PTC_TRUST_JOINS=1 (tests only): skip the joins_exact fallback, to show what it prevents
     uint32_t tune_ticket = 64;           // rays a wave reserves per ticket atomic (after its static first block of 64)
     uint32_t tune_shade_blocks_per_cu = 256; // k_shade grid cap (blocks loop over the queue beyond it; a looping block scatters its spans over the next queue, which the traversal of that queue pays for)
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the EXACT traversal kernel (8, 12 or 16)
@@ -179,6 +184,6 @@ int ptc_flatten_nodes(pt_ctx* ctx, const pt_bvh_node* h_nodes, uint32_t n_nodes,
 
 // the wide records of a binary node array already in HBM (same numbering and child order as the host-side collapse)
 int ptc_build_wide_from_nodes(pt_ctx* ctx, const float4* d_nodes, uint32_t n_internal, float4** d_wide, uint32_t* n_wide,
-                              uint32_t* max_depth, uint32_t* wide_depth);
+                              uint32_t* max_depth, uint32_t* wide_depth, bool* joins_exact);
 
 #endif

@@ -219,6 +219,33 @@ __global__ __launch_bounds__(LB_BLOCK) void k_wide(const float4* __restrict__ no
     w[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
+// The EXACT traversal does not read the boxes of an odd-depth node's two children: it re-derives each as the join of that
+// child's own two child boxes (trace_step.h).  True of every tree BVH::build or the LBVH makes; a caller's tree is checked
+// here: stats[1] = 1 if any such stored box differs from the minNum / maxNum join (the sign of a zero aside; NaN == NaN).
+__global__ __launch_bounds__(LB_BLOCK) void k_check_joins(const float4* __restrict__ nodes, const uint32_t* __restrict__ is_wide,
+                                                          uint32_t n_internal, uint32_t* __restrict__ stats) {
+    const uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (i >= n_internal || !is_wide[i]) return;
+    const float4* q = &nodes[4u * (size_t)i];
+    bool bad = false;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t r = __float_as_uint(side ? q[1].w : q[0].w);
+        if (r & PTC_LEAF_BIT) continue;
+        const float4 lo = q[side ? 2 : 0], hi = q[side ? 3 : 1];
+        const float4* c = &nodes[4u * (size_t)r];
+        const float jl[3] = {fminf(c[0].x, c[2].x), fminf(c[0].y, c[2].y), fminf(c[0].z, c[2].z)};
+        const float jh[3] = {fmaxf(c[1].x, c[3].x), fmaxf(c[1].y, c[3].y), fmaxf(c[1].z, c[3].z)};
+        const float sl[3] = {lo.x, lo.y, lo.z}, sh[3] = {hi.x, hi.y, hi.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!(sl[k] == jl[k] || (sl[k] != sl[k] && jl[k] != jl[k]))) bad = true;
+            if (!(sh[k] == jh[k] || (sh[k] != sh[k] && jh[k] != jh[k]))) bad = true;
+        }
+    }
+    if (bad) atomicOr(&stats[1], 1u);
+}
+
 // parent links of a finished binary node array (caller-supplied trees: the links are not known yet)
 __global__ __launch_bounds__(LB_BLOCK) void k_parents(const float4* __restrict__ nodes, uint32_t n_internal,
                                                       uint32_t* __restrict__ parent_of_internal) {
@@ -232,7 +259,8 @@ __global__ __launch_bounds__(LB_BLOCK) void k_parents(const float4* __restrict__
 
 // ---- caller-supplied node vectors (pt_scene_create): validate and flatten on the device -------------------------------
 // err bits: 1 leaf shape_index out of range, 2 child index not a forward preorder index, 4 node referenced by two parents
-// (so another is unreachable), 8 triangle referenced by two leaves, 16 (not an error) a child box with min > max
+// (so another is unreachable), 8 triangle referenced by two leaves, 16 (not an error) a child box with min > max or with a
+// NaN in only one of min / max on an axis
 __global__ __launch_bounds__(LB_BLOCK) void k_node_flags(const uint4* __restrict__ raw, uint32_t n_nodes, uint32_t n_tris,
                                                          uint32_t* __restrict__ is_internal, uint32_t* __restrict__ err) {
     const uint32_t i = blockIdx.x * LB_BLOCK + threadIdx.x;
@@ -269,7 +297,8 @@ __global__ __launch_bounds__(LB_BLOCK) void k_node_pack(const uint4* __restrict_
     const float lmin[3] = {__uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z)}, lmax[3] = {__uint_as_float(b0.w), __uint_as_float(b1.x), __uint_as_float(b1.y)};
     const float rmin[3] = {__uint_as_float(b1.z), __uint_as_float(b1.w), __uint_as_float(b2.x)}, rmax[3] = {__uint_as_float(b2.y), __uint_as_float(b2.z), __uint_as_float(b2.w)};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) if (lmin[k] > lmax[k] || rmin[k] > rmax[k]) bad |= 16u;
+    for (int k = 0; k < 3; ++k)         // ordered: min <= max, or both NaN (a NaN on one side only breaks the sign-select step too)
+        if (!(lmin[k] <= lmax[k] || (lmin[k] != lmin[k] && lmax[k] != lmax[k])) || !(rmin[k] <= rmax[k] || (rmin[k] != rmin[k] && rmax[k] != rmax[k]))) bad |= 16u;
     float4* q = &nodes[4u * (size_t)rank[i]];
     q[0] = make_float4(lmin[0], lmin[1], lmin[2], __uint_as_float(refs[0]));
     q[1] = make_float4(lmax[0], lmax[1], lmax[2], __uint_as_float(refs[1]));
@@ -387,8 +416,9 @@ int ptc_build_lbvh(pt_ctx* ctx, const float4* h_boxes, uint32_t n, float4** d_no
 // pt_scene_create): depths, prefix sum over odd-depth nodes, k_wide — the same kernels the LBVH build ends with, and the
 // same numbering (preorder among wide nodes) and child order as the host-side collapse in core.hip.
 int ptc_build_wide_from_nodes(pt_ctx* ctx, const float4* d_nodes, uint32_t n_internal, float4** d_wide, uint32_t* n_wide,
-                              uint32_t* max_depth, uint32_t* wide_depth) {
+                              uint32_t* max_depth, uint32_t* wide_depth, bool* joins_exact) {
     *d_wide = nullptr;
+    *joins_exact = true;
     hipStream_t s = ctx->stream;
     Scratch tmp;
     uint32_t *par_i = nullptr, *is_wide = nullptr, *wide_index = nullptr, *stats = nullptr;
@@ -400,6 +430,7 @@ int ptc_build_wide_from_nodes(pt_ctx* ctx, const float4* d_nodes, uint32_t n_int
     const uint32_t gi = (n_internal + LB_BLOCK - 1) / LB_BLOCK;
     hipLaunchKernelGGL(k_parents, dim3(gi), dim3(LB_BLOCK), 0, s, d_nodes, n_internal, par_i);
     hipLaunchKernelGGL(k_depth, dim3(gi), dim3(LB_BLOCK), 0, s, par_i, n_internal, is_wide, stats);
+    hipLaunchKernelGGL(k_check_joins, dim3(gi), dim3(LB_BLOCK), 0, s, d_nodes, is_wide, n_internal, stats);
     size_t scan_bytes = 0;
     PTC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_wide, wide_index, (int)n_internal, s));
     char* scan_tmp = nullptr;
@@ -423,6 +454,7 @@ int ptc_build_wide_from_nodes(pt_ctx* ctx, const float4* d_nodes, uint32_t n_int
     *n_wide = nw;
     *max_depth = h_stats[0];
     *wide_depth = (h_stats[0] + 1u) / 2u;
+    *joins_exact = h_stats[1] == 0u;
     return PT_OK;
 }
 

@@ -587,7 +587,9 @@ int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays
     if (n == 0) return PT_OK;
     if (n > 0xF0000000u) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "more than 0xF0000000 rays in one batch");
     const DevSceneView& v = scene->view;
-    const uint32_t mode = ctx->traversal;
+    // EXACT re-derives the boxes of an odd-depth node's children from their own children's boxes; on a caller's tree whose
+    // stored boxes are not those joins (DevSceneView::joins_exact) the frame replay, which reads the stored boxes, answers
+    const uint32_t mode = (ctx->traversal == PT_TRAVERSE_EXACT && !v.joins_exact) ? PT_TRAVERSE_REPLAY : ctx->traversal;
     // resident grid: waves_per_simd blocks of 256 per CU at most (a persistent kernel must be resident as a whole: a block
     // that starts only when another ends finds the tickets gone); fewer when the batch is small
     uint32_t per_cu = ctx->tune_blocks_per_cu;

@@ -420,3 +420,81 @@ def test_irregular_rays_and_non_finite_hits_take_the_replay_path(oracle, gpu_ctx
             print(f"mode {mode}: {int(nan_sign.sum())} of {n} rays took the sign of a NaN; {int((~same & nan_sign).sum())} of those differ from the x86 oracle")
     finally:
         gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
+
+
+def loose_tree_scene(rng):
+    """Duplicate clusters (equal-t ties: the visiting ORDER decides the answer) under a reference-built tree whose stored child
+    boxes were then padded at random - still a valid BVH (every box contains its subtree), no longer the exact joins."""
+    base = workloads.soup_scene(3000).triangles
+    t = np.concatenate([base, base[rng.integers(0, base.size, 3000)], base[:500]])
+    t = t[rng.permutation(t.size)]
+    nodes = core.bvh_build(t).copy()
+    inner = np.flatnonzero(nodes["is_leaf"] == 0)
+    pick = inner[rng.random(inner.size) < 0.4]
+    for side in ("child_l_aabb", "child_r_aabb"):
+        pad = rng.uniform(0.0, 0.05, size=(pick.size, 3)).astype(np.float32) * (rng.random((pick.size, 3)) < 0.5)
+        nodes[side]["min"][pick] -= pad
+        pad = rng.uniform(0.0, 0.05, size=(pick.size, 3)).astype(np.float32) * (rng.random((pick.size, 3)) < 0.5)
+        nodes[side]["max"][pick] += pad
+    return abi.SceneArrays(t, nodes, workloads.soup_scene(8).materials, core.sky_d65(1.0))
+
+
+def test_a_loose_caller_tree_is_answered_from_its_stored_boxes(oracle, monkeypatch):
+    """PT_TRAVERSE_EXACT re-derives the boxes of an odd-depth node's children from THEIR children's boxes, which is
+    the stored box only in a tree of exact joins.  pt_scene_create checks a caller's tree (k_check_joins); on a padded tree an
+    EXACT call is answered by the frame replay, which reads the stored boxes: EXACT, REPLAY and the oracle walking that same
+    tree agree on every ray.  With the check switched off (PTC_TRUST_JOINS=1, a test knob) the scoped kernel answers from the
+    derived boxes and parts ways with the recursion on some equal-t ties - which is what the check is for."""
+    arr = loose_tree_scene(np.random.default_rng(23))
+    rays = core.gen_primary_rays(384, 216)
+    want = oracle.trace(oracle.scene(arr), rays)
+    assert (want["tri"] != abi.PT_NO_TRIANGLE).mean() > 0.5
+    ctx = core.Context(0)
+    try:
+        sc = ctx.scene(arr)
+        for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY):
+            ctx.set_traversal(mode)
+            assert ctx.trace(sc, rays).tobytes() == want.tobytes(), mode
+        ctx.set_traversal(abi.PT_TRAVERSE_MIN_T)          # a minimum-t hit on any valid tree
+        got = ctx.trace(sc, rays)
+        assert np.array_equal(got["t"], want["t"])
+        # the same tree rendered: the integrator's queued launches take the fallback too
+        ctx.set_traversal(abi.PT_TRAVERSE_EXACT)
+        img = ctx.render(sc, 96, 54, 0, 2, 2, seed=3)
+        ref = oracle.render(oracle.scene(arr), 96, 54, 0, 2, 2, seed=3)
+        assert ((img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))).all()
+    finally:
+        ctx.close()
+    # a tight tree keeps the scoped kernel: nothing to fall back from (checked by the kernel name in the profiles); and the
+    # knob that trusts a loose tree shows the difference the check prevents
+    monkeypatch.setenv("PTC_TRUST_JOINS", "1")
+    ctx = core.Context(0)
+    try:
+        ctx.set_traversal(abi.PT_TRAVERSE_EXACT)
+        got = ctx.trace(ctx.scene(arr), rays)
+        differing = int((got["tri"] != want["tri"]).sum())
+        assert np.array_equal(got["t"], want["t"]) and differing > 0, differing
+    finally:
+        ctx.close()
+
+
+def test_a_box_with_nan_on_one_side_only_rules_out_the_sign_select_step(oracle):
+    """a caller box with NaN in just one of min / max on an axis passes a `min > max` test; the sign-select record
+    step would load the NaN plane as `near` where minNum / maxNum drop it.  Such a scene must take the general step (and, its
+    boxes not being joins, the replay): every mode equals the oracle walking the same nodes."""
+    arr = workloads.soup_scene(2000)
+    nodes = arr.nodes.copy()
+    inner = np.flatnonzero(nodes["is_leaf"] == 0)
+    nodes["child_l_aabb"]["min"][inner[5], 0] = np.nan
+    nodes["child_r_aabb"]["max"][inner[40], 2] = np.nan
+    arr2 = abi.SceneArrays(arr.triangles, nodes, arr.materials, arr.sky)
+    rays = core.gen_primary_rays(256, 144)
+    want = oracle.trace(oracle.scene(arr2), rays)
+    ctx = core.Context(0)
+    try:
+        sc = ctx.scene(arr2)
+        for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY):
+            ctx.set_traversal(mode)
+            assert ctx.trace(sc, rays).tobytes() == want.tobytes(), mode
+    finally:
+        ctx.close()
