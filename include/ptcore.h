@@ -215,8 +215,10 @@ void pt_host_free(void* p);
 int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
                          const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out);
 
-/* The same call for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc).  No counterpart in the reference.  pt_trace_closest_dev grows three device buffers on demand (stack spill
+/* The same call for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, processes whose
+ * HBM is spoken for).  No counterpart in the reference.  Like pt_trace_closest_dev it runs on the library's own stream, times
+ * itself with events and RETURNS AFTER THE KERNELS HAVE COMPLETED: it is a blocking call and cannot be captured into a HIP
+ * graph (what it removes is the allocation, not the synchronisation).  pt_trace_closest_dev grows three device buffers on demand (stack spill
  * columns, ticket words, the redo list of PT_TRAVERSE_EXACT); this variant runs the same kernels with those buffers carved
  * out of one fixed device array that every GPU the library runs on holds until the process ends (about 144 MiB), and calls
  * no hipMalloc / hipFree.  Same results, bit for bit.  Limits, reported as PT_ERR_UNSUPPORTED with a message: at most

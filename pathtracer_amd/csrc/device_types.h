@@ -144,6 +144,10 @@ int ptc_timed_event(pt_ctx* ctx, size_t i);
     } while (0)
 
 #define PTC_TICKET_BYTES 8192u
+#ifndef PTC_SHARDS
+#define PTC_SHARDS 8u             /* ticket words / contiguous ray shards per launch of the persistent traversal kernels (power of
+                                     two not required); every grid is a multiple of it (trace.hip, trace_noalloc.hip) */
+#endif
 
 // Where one traversal launch keeps its device-side scratch when that is not the context's own (grown-on-demand) buffers:
 // the allocation-free entry point (trace_noalloc.hip) points these at its file-scope device array.

@@ -44,9 +44,6 @@
 #include "trace_step.h"
 
 #define PTC_BLOCK 256
-#ifndef PTC_SHARDS
-#define PTC_SHARDS 8u             /* ticket words / contiguous ray shards per launch (power of two not required) */
-#endif
 #ifndef PTC_POPS_PER_TRIP
 #define PTC_POPS_PER_TRIP 1
 #endif

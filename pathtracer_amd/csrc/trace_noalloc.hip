@@ -1,5 +1,7 @@
 // trace_noalloc.hip — pt_trace_closest_dev_noalloc: the closest-hit entry point for callers that cannot allocate
-// (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+// (tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  It is a BLOCKING call like
+// pt_trace_closest_dev (the library's own stream, events around the kernels, hipEventSynchronize before it returns), so it
+// cannot be captured into a HIP graph: what it removes is the allocation, not the synchronisation.
 //
 // pt_trace_closest_dev keeps three scratch buffers in the context and grows them with hipMalloc on demand: the HBM columns
 // the per-lane traversal stacks spill to, the ticket words of the persistent kernels, and the redo list of
@@ -14,7 +16,7 @@
 //   * all contexts on one GPU share that GPU's array, and it keeps the last call's contents: every call clears the ticket
 //     words it depends on first, and calls that overlap in time on one GPU race (one call at a time per GPU);
 //   * limits, rejected with PT_ERR_UNSUPPORTED and a message: at most PT_NOALLOC_MAX_RAYS rays per call; the scene's tree
-//     must be shallow enough for at least 8 blocks' worth of stack columns to fit (the grid is cut down to what fits, so
+//     must be shallow enough for at least PTC_SHARDS (8) blocks' worth of stack columns to fit (the grid is cut down to what fits, so
 //     deep scenes run with fewer resident waves than pt_trace_closest_dev would use).
 #include <hip/hip_runtime.h>
 
@@ -67,10 +69,11 @@ static int pt_trace_closest_dev_noalloc_body(pt_ctx* ctx, const pt_scene* scene,
     DeviceScratch& d = g_dev[ctx->device];
     // the stack columns need `depth` 8-byte entries per resident thread: cut the grid down to what the fixed area holds
     const DevSceneView& v = scene->view;
-    const size_t depth = ptc_spill_depth(v, ctx->traversal);
+    const uint32_t mode = (ctx->traversal == PT_TRAVERSE_EXACT && !v.joins_exact) ? PT_TRAVERSE_REPLAY : ctx->traversal;   // as ptc_launch_trace_in
+    const size_t depth = ptc_spill_depth(v, mode);
     const size_t per_block = depth * 256u * sizeof(uint2);
-    const size_t fit = (PTC_NOALLOC_SPILL_BYTES / per_block) / 8u * 8u;
-    if (fit < 8u) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_trace_closest_dev_noalloc: the scene's BVH is too deep for the fixed traversal scratch");
+    const size_t fit = (PTC_NOALLOC_SPILL_BYTES / per_block) / PTC_SHARDS * PTC_SHARDS;      // the grid is a multiple of PTC_SHARDS
+    if (fit < PTC_SHARDS) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "pt_trace_closest_dev_noalloc: the scene's BVH is too deep for the fixed traversal scratch");
     ptc_trace_scratch s{};
     s.spill = d.ptr;
     s.spill_bytes = PTC_NOALLOC_SPILL_BYTES;

@@ -2,7 +2,8 @@
 columns, ticket words and redo list live in a fixed file-scope device array (trace_noalloc.hip) instead of the context's
 grown-on-demand buffers.  Called through the C ABI, its output must equal pt_trace_closest_dev's bit for bit: on two calls
 in a row, the second with a smaller input (the array keeps the first call's contents), in every traversal mode, with and
-without start triangles; sizes beyond the stated maximum are refused with a clear error.
+without start triangles; sizes beyond the stated maximum are refused with a clear error; and the free device memory does not
+move across its calls on a context that has never run the allocating entry point.
 
 Collected last on purpose (the round's end runs pytest -x): passes alone in a fresh process and after the other tests."""
 import numpy as np
@@ -53,3 +54,65 @@ def test_noalloc_entry_point_equals_the_allocating_one(gpu_ctx):
     rc = lib.pt_trace_closest_dev_noalloc(gpu_ctx.handle, sc.handle, core.C.c_void_p(d_rays.data_ptr()), None,
                                           abi.PT_NOALLOC_MAX_RAYS + 1, core.C.c_void_p(got.data_ptr()))
     assert rc == abi.PT_ERR_UNSUPPORTED and b"PT_NOALLOC_MAX_RAYS" in lib.pt_last_error(gpu_ctx.handle)
+
+
+def _chain(n):
+    from tests.test_gpu_trace import chain_scene
+    return chain_scene(n)
+
+
+def test_noalloc_allocates_nothing_and_knows_its_limits(oracle):
+    """A FRESH context that only ever runs the no-alloc entry point (so none of the context's grown-on-demand buffers exist
+    and an accidental ptc_reserve could not hide behind an earlier call): after one small warm-up call (code objects, kernel
+    argument pools) the free device memory is the same before and after larger calls in every mode.  A 599-level chain tree
+    takes the reduced-grid path (its stack columns are deep, fewer blocks fit the fixed array); a 4095-level chain is
+    refused for PT_TRAVERSE_EXACT with a message and still answered by REPLAY, whose columns are half as deep."""
+    import torch
+    lib = core.lib()
+    ctx = core.Context(0)
+    try:
+        arr, deep, too_deep = workloads.soup_scene(50_000), _chain(600), _chain(4096)
+        sc, sc_deep, sc_too_deep = ctx.scene(arr), ctx.scene(deep), ctx.scene(too_deep)
+        assert sc_deep.info().max_depth == 599 and sc_too_deep.info().max_depth == 4095
+        rays = core.gen_primary_rays(640, 360)
+        n = rays.size
+        d_rays = _dev(torch, rays)
+        got = torch.zeros((n, 16), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.set_traversal(abi.PT_TRAVERSE_MIN_T)
+        ctx.trace_dev_noalloc(sc, d_rays.data_ptr(), 0, 257, got.data_ptr())          # warm-up: small, the cheapest mode
+        ctx.set_traversal(abi.PT_TRAVERSE_REPLAY)
+        ctx.trace_dev_noalloc(sc, d_rays.data_ptr(), 0, 257, got.data_ptr())
+        ctx.set_traversal(abi.PT_TRAVERSE_EXACT)
+        ctx.trace_dev_noalloc(sc, d_rays.data_ptr(), 0, 257, got.data_ptr())
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        results = {}
+        for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_MIN_T, abi.PT_TRAVERSE_REPLAY):
+            ctx.set_traversal(mode)
+            for name, s in (("soup", sc), ("deep", sc_deep)):
+                ctx.trace_dev_noalloc(s, d_rays.data_ptr(), 0, n, got.data_ptr())
+                torch.cuda.synchronize()
+                results[(mode, name)] = got.cpu().numpy().copy()
+        # too deep for the fixed array in EXACT (4 entries per wide level: 8 196 x 2 KiB per block, fewer than 8 blocks fit) ...
+        ctx.set_traversal(abi.PT_TRAVERSE_EXACT)
+        rc = lib.pt_trace_closest_dev_noalloc(ctx.handle, sc_too_deep.handle, core.C.c_void_p(d_rays.data_ptr()), None, 4096,
+                                              core.C.c_void_p(got.data_ptr()))
+        assert rc == abi.PT_ERR_UNSUPPORTED and b"too deep" in lib.pt_last_error(ctx.handle)
+        # ... and fine for REPLAY (one frame per binary level)
+        ctx.set_traversal(abi.PT_TRAVERSE_REPLAY)
+        ctx.trace_dev_noalloc(sc_too_deep, d_rays.data_ptr(), 0, 4096, got.data_ptr())
+        torch.cuda.synchronize()
+        too_deep_hits = got[:4096].cpu().numpy().copy()
+        free_after = torch.cuda.mem_get_info()[0]
+        assert free_after == free_before, (free_before, free_after)
+        # what those calls returned is the oracle's answer (the deep trees too: capped grid, long stack columns)
+        for name, a in (("soup", arr), ("deep", deep)):
+            want = oracle.trace(oracle.scene(a), rays)
+            for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY):
+                assert results[(mode, name)].tobytes() == want.tobytes(), (mode, name)
+            assert np.array_equal(results[(abi.PT_TRAVERSE_MIN_T, name)].view(np.uint32).reshape(-1, 4)[:, 1], want["t"].view(np.uint32)), name
+        want = oracle.trace(oracle.scene(too_deep), rays[:4096])
+        assert too_deep_hits.tobytes() == want.tobytes()
+    finally:
+        ctx.close()
