@@ -64,14 +64,16 @@ typedef struct pt_triangle {
     uint32_t flags;
 } pt_triangle;                   /* 104 bytes */
 
-/* Texture<P> (material.rs:80-84).  Bilinear is never constructed by the reference loader
- * (material.rs:215,228,246,249) and is not part of the ABI. */
-#define PT_TEX_FLAT    0u
-#define PT_TEX_NEAREST 1u
+/* Texture<P> (material.rs:80-84).  Bilinear (material.rs:101-123) is defined by the reference but never constructed by
+ * its loader (Material::from_mtl builds Nearest / Flat only: material.rs:215,228,246,249); a host that builds its own
+ * materials can ask for it. */
+#define PT_TEX_FLAT     0u
+#define PT_TEX_NEAREST  1u
+#define PT_TEX_BILINEAR 2u
 typedef struct pt_texture {
     uint32_t kind;
     float    value[3];   /* Flat: linear-sRGB colour, or value[0] for a scalar (dissolve) texture */
-    uint32_t image;      /* Nearest: index into pt_scene_desc.images                               */
+    uint32_t image;      /* Nearest / Bilinear: index into pt_scene_desc.images (< 2^31)           */
 } pt_texture;
 
 /* Image<P> (material.rs:12-16): row-major, (x, y) at texels[(x + y*width)*channels]. */

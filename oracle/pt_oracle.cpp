@@ -423,7 +423,7 @@ inline float rem_euclid1(float x) {        // f32::rem_euclid(1.0)
 }
 
 struct Scene;
-// Texture::sample :90-100 (Nearest) / :124 (Flat).  channels==3 -> colour, 1 -> value in .x
+// Texture::sample :90-100 (Nearest) / :101-123 (Bilinear) / :124 (Flat).  channels==3 -> colour, 1 -> value in .x
 V3 texture_sample(const Scene& sc, const pt_texture& t, float u, float v);
 
 struct Sample { float emit[NW]; float weight[NW]; Ray new_ray; };
@@ -570,13 +570,31 @@ struct Scene {
 
 V3 texture_sample(const Scene& sc, const pt_texture& t, float u, float v) {
     if (t.kind == PT_TEX_FLAT) return {t.value[0], t.value[1], t.value[2]};               // :124
-    const Image& im = sc.images[t.image];                                                 // :92-100
-    uint32_t x = pt_f2usize(std::floor(rem_euclid1(u) * (float)im.w));
-    uint32_t y = pt_f2usize(std::floor((1.0f - rem_euclid1(v)) * (float)im.h));
-    x %= im.w; y %= im.h;
-    const float* p = &im.texels[((size_t)x + (size_t)y * im.w) * im.ch];
-    if (im.ch == 3) return {p[0], p[1], p[2]};
-    return {p[0], p[0], p[0]};
+    const Image& im = sc.images[t.image];
+    auto texel = [&](uint32_t x, uint32_t y) -> V3 {                                      // Index<(u32, u32)> :28-37
+        const float* p = &im.texels[((size_t)(x % im.w) + (size_t)(y % im.h) * im.w) * im.ch];
+        if (im.ch == 3) return {p[0], p[1], p[2]};
+        return {p[0], p[0], p[0]};
+    };
+    if (t.kind == PT_TEX_NEAREST) {                                                       // :92-100
+        uint32_t x = pt_f2usize(std::floor(rem_euclid1(u) * (float)im.w));
+        uint32_t y = pt_f2usize(std::floor((1.0f - rem_euclid1(v)) * (float)im.h));
+        return texel(x, y);
+    }
+    // Texture::Bilinear :101-123
+    const float x = rem_euclid1(u) * (float)im.w;                                         // :105
+    const float y = (1.0f - rem_euclid1(v)) * (float)im.h;                                // :106
+    const uint32_t x0 = pt_f2usize(std::floor(x)), y0 = pt_f2usize(std::floor(y));        // :108-109
+    const float t_x = x - std::floor(x), t_y = y - std::floor(y);                         // :111-112
+    const V3 p00 = texel(x0, y0), p10 = texel(x0 + 1u, y0), p01 = texel(x0, y0 + 1u), p11 = texel(x0 + 1u, y0 + 1u);   // :114-117
+    V3 out;
+    const float* a = &p00.x; const float* b = &p10.x; const float* c = &p01.x; const float* d = &p11.x; float* o = &out.x;
+    for (int k = 0; k < 3; ++k) {
+        const float p0 = a[k] * (1.0f - t_x) + b[k] * t_x;                                // :119
+        const float p1 = c[k] * (1.0f - t_x) + d[k] * t_x;                                // :120
+        o[k] = p0 * (1.0f - t_y) + p1 * t_y;                                              // :122
+    }
+    return out;
 }
 
 // scene.rs:284-305
@@ -959,6 +977,14 @@ void pto_trace_globalbest_stats(const pto_scene* sc, const pt_ray* rays, uint64_
     }
     counters[0] += nodes; counters[1] += tris; counters[2] += sumdepth;
     counters[3] = std::max(counters[3], maxdepth);
+}
+
+// Texture::sample (material.rs:90-124) on image `image` of the scene: kind = PT_TEX_NEAREST / PT_TEX_BILINEAR
+void pto_texture_sample(const pto_scene* sc, uint32_t kind, uint32_t image, float u, float v, float out[3]) {
+    pt_texture t{};
+    t.kind = kind; t.image = image;
+    const V3 c = texture_sample(sc->s, t, u, v);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z;
 }
 
 // evaluate_sky for one ray direction

@@ -19,6 +19,7 @@ PT_TRI_HAS_UV = 1
 PT_TRI_HAS_NORMALS = 2
 PT_TEX_FLAT = 0
 PT_TEX_NEAREST = 1
+PT_TEX_BILINEAR = 2
 PT_EMIT_NULL = 0
 PT_EMIT_ABSORBED_D65 = 1
 PT_SKY_D65 = 0

@@ -216,8 +216,8 @@ inline void cross3(const float a[3], const float b[3], float o[3]) {
 
 int check_texture(pt_ctx* ctx, const pt_texture& t, const pt_scene_desc* d, uint32_t channels, const char* what) {
     if (t.kind == PT_TEX_FLAT) return PT_OK;
-    if (t.kind != PT_TEX_NEAREST) return ptc_fail(ctx, PT_ERR_INVALID, std::string(what) + ": unknown texture kind");
-    if (t.image >= d->n_images) return ptc_fail(ctx, PT_ERR_INVALID, std::string(what) + ": image index out of range");
+    if (t.kind != PT_TEX_NEAREST && t.kind != PT_TEX_BILINEAR) return ptc_fail(ctx, PT_ERR_INVALID, std::string(what) + ": unknown texture kind");
+    if (t.image >= d->n_images || t.image >= PTC_IMG_BILINEAR) return ptc_fail(ctx, PT_ERR_INVALID, std::string(what) + ": image index out of range");
     if (d->images[t.image].channels != channels)
         return ptc_fail(ctx, PT_ERR_INVALID, std::string(what) + ": image has the wrong channel count");
     return PT_OK;
@@ -457,11 +457,15 @@ static int pt_scene_create_ex_body(pt_ctx* ctx, const pt_scene_desc* d, uint32_t
         if (m.emit_kind == PT_EMIT_ABSORBED_D65 && (rc = check_texture(ctx, m.absorption, d, 3, "pt_scene_create: material.absorption")) != PT_OK) return rc;
         DevMaterial& o = mats[i];
         for (int k = 0; k < 3; ++k) { o.diffuse[k] = m.diffuse.value[k]; o.absorb[k] = m.absorption.value[k]; }
-        o.diffuse_img = m.diffuse.kind == PT_TEX_NEAREST ? m.diffuse.image : 0xFFFFFFFFu;
-        o.absorb_img = (m.emit_kind == PT_EMIT_ABSORBED_D65 && m.absorption.kind == PT_TEX_NEAREST) ? m.absorption.image : 0xFFFFFFFFu;
+        // image reference of a texture: 0xFFFFFFFF = Flat, else the image index, bit 31 set for Bilinear (DevMaterial)
+        auto img_ref = [](const pt_texture& t) -> uint32_t {
+            return t.kind == PT_TEX_NEAREST ? t.image : t.kind == PT_TEX_BILINEAR ? (t.image | PTC_IMG_BILINEAR) : 0xFFFFFFFFu;
+        };
+        o.diffuse_img = img_ref(m.diffuse);
+        o.absorb_img = m.emit_kind == PT_EMIT_ABSORBED_D65 ? img_ref(m.absorption) : 0xFFFFFFFFu;
         o.base_dissolve = m.base_dissolve;
         o.dissolve_value = m.dissolve.value[0];
-        o.dissolve_img = m.dissolve.kind == PT_TEX_NEAREST ? m.dissolve.image : 0xFFFFFFFFu;
+        o.dissolve_img = img_ref(m.dissolve);
         o.emit_kind = m.emit_kind;
     }
 

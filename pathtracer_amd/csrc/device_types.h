@@ -41,8 +41,9 @@
 //   s1 = { uv1.x, uv1.y, uv2.x, uv2.y }
 //   s2 = { vn0.x, vn0.y, vn0.z, vn1.x }   s3 = { vn1.y, vn1.z, vn2.x, vn2.y }   s4 = { vn2.z, 0, 0, 0 }
 
+#define PTC_IMG_BILINEAR 0x80000000u   /* in a DevMaterial image reference: Texture::Bilinear instead of Nearest */
 struct DevMaterial {        // 48 B
-    float diffuse[3];   uint32_t diffuse_img;      // 0xFFFFFFFF = Flat
+    float diffuse[3];   uint32_t diffuse_img;      // 0xFFFFFFFF = Flat, else image index | PTC_IMG_BILINEAR
     float absorb[3];    uint32_t absorb_img;
     float base_dissolve; float dissolve_value; uint32_t dissolve_img; uint32_t emit_kind;
 };

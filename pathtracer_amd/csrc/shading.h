@@ -3,7 +3,7 @@
 //   Color<SRGB>::reflectance_at_one     color.rs:41-54
 //   Color<XYZ>::from_wavelength         color.rs:72-93
 //   D65::sample_one                     material.rs:132-141
-//   Texture::sample (Flat / Nearest)    material.rs:90-100,124
+//   Texture::sample (Flat / Nearest / Bilinear)    material.rs:90-124
 //   HosekWilkieSkyModel::radiance_one / solar_radiance_one and helpers   hosek_wilkie.rs:74-131,306-383
 //   Scene::evaluate_sky                 scene.rs:284-305
 //
@@ -123,13 +123,31 @@ __device__ __forceinline__ float rem_euclid1(float x) {
 __device__ __forceinline__ void texture_rgb(const DevSceneView& sc, uint32_t img, const float flat[3], float u,
                                             float v, float& r, float& g, float& b) {
     if (img == 0xFFFFFFFFu) { r = flat[0]; g = flat[1]; b = flat[2]; return; }
-    const DevImage im = sc.images[img];
-    uint32_t x = pt_f2usize(pt_floor(rem_euclid1(u) * (float)im.width));
-    uint32_t y = pt_f2usize(pt_floor((1.0f - rem_euclid1(v)) * (float)im.height));
-    x %= im.width; y %= im.height;
-    const float* p = sc.texels + im.offset + ((size_t)x + (size_t)y * im.width) * im.channels;
-    if (im.channels == 3u) { r = p[0]; g = p[1]; b = p[2]; }
-    else { r = g = b = p[0]; }
+    const DevImage im = sc.images[img & ~PTC_IMG_BILINEAR];
+    const float fx = rem_euclid1(u) * (float)im.width, fy = (1.0f - rem_euclid1(v)) * (float)im.height;
+    const uint32_t x0 = pt_f2usize(pt_floor(fx)), y0 = pt_f2usize(pt_floor(fy));       // `as u32`: saturating, NaN -> 0
+    const float* base = sc.texels + im.offset;
+    auto texel = [&](uint32_t x, uint32_t y, float& tr, float& tg, float& tb) {
+        const float* p = base + ((size_t)(x % im.width) + (size_t)(y % im.height) * im.width) * im.channels;
+        if (im.channels == 3u) { tr = p[0]; tg = p[1]; tb = p[2]; }
+        else { tr = tg = tb = p[0]; }
+    };
+    if (!(img & PTC_IMG_BILINEAR)) { texel(x0, y0, r, g, b); return; }                 // Nearest, material.rs:92-100
+    // Bilinear, material.rs:101-123: p0 = p00 * (1 - tx) + p10 * tx, p1 = p01 * (1 - tx) + p11 * tx, p0 * (1 - ty) + p1 * ty
+    const float tx = fx - pt_floor(fx), ty = fy - pt_floor(fy);
+    float a[3], c[3], d[3], e[3];
+    texel(x0, y0, a[0], a[1], a[2]);
+    texel(x0 + 1u, y0, c[0], c[1], c[2]);
+    texel(x0, y0 + 1u, d[0], d[1], d[2]);
+    texel(x0 + 1u, y0 + 1u, e[0], e[1], e[2]);
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p0 = a[k] * (1.0f - tx) + c[k] * tx;
+        const float p1 = d[k] * (1.0f - tx) + e[k] * tx;
+        o[k] = p0 * (1.0f - ty) + p1 * ty;
+    }
+    r = o[0]; g = o[1]; b = o[2];
 }
 
 // ---- Hosek-Wilkie ---------------------------------------------------------------------------------

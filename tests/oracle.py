@@ -67,6 +67,7 @@ class Oracle:
             "pto_trace_brute": (None, [vp, vp, vp, u64, vp, i32]),
             "pto_trace_globalbest_stats": (None, [vp, vp, u64, vp, C.POINTER(u64), vp]),
             "pto_evaluate_sky": (None, [vp, pf, pf, pf]),
+            "pto_texture_sample": (None, [vp, u32, u32, f32, f32, pf]),
             "pto_render": (None, [vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp, C.POINTER(u64), i32]),
             "pto_math": (f32, [i32, f32]),
             "pto_philox": (None, [C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
@@ -184,6 +185,11 @@ class Oracle:
         pr = np.zeros((rays.size, 3), dtype=np.uint32) if per_ray else None
         self.L.pto_trace_globalbest_stats(scene.handle, abi.ptr(rays), rays.size, abi.ptr(out), cnt, abi.ptr(pr))
         return (out, list(cnt), pr) if per_ray else (out, list(cnt))
+
+    def texture_sample(self, scene, kind, image, u, v):
+        out = (C.c_float * 3)()
+        self.L.pto_texture_sample(scene.handle, kind, image, float(u), float(v), out)
+        return np.array(out[:], dtype=np.float32)
 
     def evaluate_sky(self, scene, d, wl):
         out = (C.c_float * 8)()

@@ -53,6 +53,8 @@ def test_bad_scene_descriptions(gpu_ctx):
     expect_invalid(lambda a: a.nodes["child_r_index"].__setitem__(0, 10 ** 6))
     expect_invalid(lambda a: a.materials["emit_kind"].__setitem__(1, 5))
     expect_invalid(lambda a: a.materials["diffuse"]["kind"].__setitem__(1, abi.PT_TEX_NEAREST))      # image index with no images
+    expect_invalid(lambda a: a.materials["diffuse"]["kind"].__setitem__(1, abi.PT_TEX_BILINEAR))
+    expect_invalid(lambda a: a.materials["diffuse"]["kind"].__setitem__(1, 3))                       # no such Texture variant
 
     def dup_leaf(a):
         leaves = np.flatnonzero(a.nodes["is_leaf"])

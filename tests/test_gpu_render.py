@@ -87,6 +87,53 @@ def test_dissolve_textures_uv_and_vertex_normals(oracle, gpu_ctx):
     compare_images(got, want, "materials")
 
 
+def test_bilinear_textures_on_a_quad_and_in_the_soup(oracle, gpu_ctx):
+    """Texture::Bilinear (material.rs:101-123; PT_TEX_BILINEAR - the reference's loader never builds one, a host may): a
+    textured, emissive, partly dissolved quad facing the camera with uv beyond [0, 1] (wrap-around texels), and the soup with
+    bilinear diffuse / dissolve / absorption textures next to Nearest ones on the same images.  Bit for bit the oracle's image."""
+    rng = np.random.default_rng(17)
+    images = [rng.uniform(0, 1, size=(7, 5, 3)).astype(np.float32), rng.uniform(0.3, 1, size=(4, 9)).astype(np.float32)]
+    quad = np.zeros(2, dtype=abi.TRIANGLE)
+    a, b, c, d = (-1.2, -0.8, -3.0), (1.2, -0.8, -3.0), (1.2, 0.8, -3.0), (-1.2, 0.8, -3.0)
+    uva, uvb, uvc, uvd = (-0.5, -0.25), (1.75, -0.25), (1.75, 1.5), (-0.5, 1.5)
+    for k, (p, uv) in enumerate((((a, b, c), (uva, uvb, uvc)), ((a, c, d), (uva, uvc, uvd)))):
+        quad[k]["a"], quad[k]["b"], quad[k]["c"] = p
+        quad[k]["uv"] = uv
+        quad[k]["flags"] = abi.PT_TRI_HAS_UV
+        quad[k]["material_index"] = 1
+    m = abi.default_material()
+    m["diffuse"]["kind"], m["diffuse"]["image"] = abi.PT_TEX_BILINEAR, 0
+    m["emit_kind"] = abi.PT_EMIT_ABSORBED_D65
+    m["absorption"]["kind"], m["absorption"]["image"] = abi.PT_TEX_BILINEAR, 0
+    m["base_dissolve"] = 1.0
+    m["dissolve"]["kind"], m["dissolve"]["image"] = abi.PT_TEX_BILINEAR, 1
+    arr = abi.SceneArrays(quad, core.bvh_build(quad), np.array([abi.default_material(), m], dtype=abi.MATERIAL), core.sky_d65(0.2), images)
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 160, 120, 0, 4, 4, seed=6)
+    want = oracle.render(oracle.scene(arr), 160, 120, 0, 4, 4, seed=6)
+    compare_images(got, want, "bilinear quad", max_diff_frac=0.0, mean_rel=0.0)
+    # the texture shows: neighbouring pixels differ smoothly, and the image is not the Nearest one
+    m2 = m.copy()
+    for k in ("diffuse", "absorption", "dissolve"):
+        m2[k]["kind"] = abi.PT_TEX_NEAREST
+    arr_n = abi.SceneArrays(quad, arr.nodes, np.array([abi.default_material(), m2], dtype=abi.MATERIAL), core.sky_d65(0.2), images)
+    near = gpu_ctx.render(gpu_ctx.scene(arr_n), 160, 120, 0, 4, 4, seed=6)
+    assert (near != got).any(axis=-1).mean() > 0.2
+    compare_images(near, oracle.render(oracle.scene(arr_n), 160, 120, 0, 4, 4, seed=6), "nearest quad", max_diff_frac=0.0, mean_rel=0.0)
+
+    tris = workloads.soup_triangles(5_000)
+    tris["flags"] = np.where(np.arange(tris.size) % 3 != 0, abi.PT_TRI_HAS_UV, 0)
+    tris["uv"] = rng.uniform(-2, 2, size=(tris.size, 3, 2)).astype(np.float32)
+    mats = workloads.soup_materials()
+    mats[2]["diffuse"]["kind"] = abi.PT_TEX_BILINEAR; mats[2]["diffuse"]["image"] = 0
+    mats[3]["dissolve"]["kind"] = abi.PT_TEX_BILINEAR; mats[3]["dissolve"]["image"] = 1
+    mats[4]["diffuse"]["kind"] = abi.PT_TEX_NEAREST; mats[4]["diffuse"]["image"] = 0
+    mats[8]["absorption"]["kind"] = abi.PT_TEX_BILINEAR; mats[8]["absorption"]["image"] = 0
+    arr = abi.SceneArrays(tris, core.bvh_build(tris), mats, core.sky_d65(0.5), images)
+    got = gpu_ctx.render(gpu_ctx.scene(arr), 128, 72, 0, 4, 4, seed=12)
+    want = oracle.render(oracle.scene(arr), 128, 72, 0, 4, 4, seed=12)
+    compare_images(got, want, "bilinear soup", max_diff_frac=0.0, mean_rel=0.0)
+
+
 def test_sample_ranges_compose(oracle, gpu_ctx):
     """PT_RENDER_SUM over [0,3) + [3,5) equals the 5-spp image up to f32 summation order, and each
     partial equals the oracle's partial exactly."""

@@ -177,3 +177,45 @@ def test_empty_and_single_triangle_scenes(oracle):
     one = oracle.scene(workloads.soup_scene(1))
     nodes = one.nodes()
     assert nodes.size == 1 and nodes[0]["is_leaf"] == 1                  # bvh.rs:154-159
+
+
+def test_texture_bilinear_against_a_numpy_restatement(oracle):
+    """Texture::Bilinear (material.rs:101-123): the reference defines it, its loader never builds one, and it holds no vector
+    for it (parity unpinned) - the oracle's restatement is checked here against an independent one written from the same
+    lines in numpy binary32: x = rem_euclid(u, 1) * W, y = (1 - rem_euclid(v, 1)) * H, the four texels around (floor x,
+    floor y) with rem_euclid wrap, p0 = p00 (1 - tx) + p10 tx, p1 = p01 (1 - tx) + p11 tx, p0 (1 - ty) + p1 ty."""
+    from pathtracer_amd import abi, core, workloads
+    f32 = np.float32
+    rng = np.random.default_rng(8)
+    img3, img1 = rng.uniform(0, 1, size=(5, 7, 3)).astype(f32), rng.uniform(0, 1, size=(3, 4)).astype(f32)      # (H, W, ch)
+    arr = abi.SceneArrays(workloads.box_triangles(), core.bvh_build(workloads.box_triangles()), workloads.box_materials(),
+                          core.sky_d65(1.0), [img3, img1])
+    sc = oracle.scene(arr)
+
+    def rem1(x):
+        r = np.fmod(f32(x), f32(1.0))
+        return f32(r + f32(1.0)) if r < 0 else f32(r)
+
+    def bilinear(img, u, v):
+        h, w = img.shape[0], img.shape[1]
+        x, y = f32(rem1(u) * f32(w)), f32(f32(f32(1.0) - rem1(v)) * f32(h))
+        x0, y0 = int(np.floor(x)), int(np.floor(y))
+        tx, ty = f32(x - np.floor(x)), f32(y - np.floor(y))
+        px = lambda i, j: np.atleast_1d(img[j % h, i % w]).astype(f32)
+        p0 = (px(x0, y0) * f32(f32(1.0) - tx)).astype(f32) + (px(x0 + 1, y0) * tx).astype(f32)
+        p1 = (px(x0, y0 + 1) * f32(f32(1.0) - tx)).astype(f32) + (px(x0 + 1, y0 + 1) * tx).astype(f32)
+        return ((p0 * f32(f32(1.0) - ty)).astype(f32) + (p1 * ty).astype(f32)).astype(f32)
+
+    uvs = [(0.0, 0.0), (0.5, 0.5), (0.999999, 0.000001), (1.0, 1.0), (-0.25, 2.75), (3.1, -7.9), (0.1428571, 0.2)]
+    uvs += [tuple(p) for p in rng.uniform(-3, 3, size=(200, 2))]
+    for u, v in uvs:
+        got3 = oracle.texture_sample(sc, abi.PT_TEX_BILINEAR, 0, u, v)
+        assert np.array_equal(got3.view(np.uint32), bilinear(img3, u, v).view(np.uint32)), (u, v)
+        got1 = oracle.texture_sample(sc, abi.PT_TEX_BILINEAR, 1, u, v)
+        assert got1[0].view(np.uint32) == bilinear(img1, u, v)[0].view(np.uint32) and got1[0] == got1[1] == got1[2], (u, v)
+        # Nearest keeps its old meaning (material.rs:92-100)
+        h, w = img3.shape[:2]
+        x, y = int(np.floor(f32(rem1(u) * f32(w)))), int(np.floor(f32(f32(f32(1.0) - rem1(v)) * f32(h))))
+        assert np.array_equal(oracle.texture_sample(sc, abi.PT_TEX_NEAREST, 0, u, v), img3[y % h, x % w]), (u, v)
+    # at a texel corner the four weights collapse to one texel; halfway it is the mean of two
+    assert np.allclose(oracle.texture_sample(sc, abi.PT_TEX_BILINEAR, 0, 2.5 / 7, 1 - 1.0 / 5), 0.5 * (img3[1, 2] + img3[1, 3]), atol=1e-6)
