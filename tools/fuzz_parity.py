@@ -3,7 +3,7 @@
 duplicated triangles, flat and huge/small extents), random rays (axis-parallel directions, origins on box faces,
 zero components), all traversal modes + the device-built BVH, and small renders with random materials
 (dissolve, emitters, nearest-sampled textures with uv outside [0,1], interpolated vertex normals, random Hosek-Wilkie suns, cameras).  Prints one JSON line; every tree (the reference's, and the device-built one read back with pt_scene_get_bvh) is checked against the CPU restatement walking that same tree: EXACT (the default) and REPLAY must agree on every bit; MIN_T may differ only at equal-t ties and, counted separately, where two hits lie within 4 ulp of each other.
-usage: tools/fuzz_parity.py [--seeds N]"""
+usage: tools/fuzz_parity.py [--seeds N] [--first-seed S] [--seed-list a,b,c] [--rays N]"""
 import argparse
 import json
 import os
@@ -22,7 +22,9 @@ ap.add_argument("--seeds", type=int, default=40)
 ap.add_argument("--sizes", type=int, nargs="*", default=list(__import__("tests.fuzz_scenes", fromlist=["DEFAULT_SIZES"]).DEFAULT_SIZES), help="triangle counts to draw from")
 ap.add_argument("--rays", type=int, default=20000)
 ap.add_argument("--first-seed", type=int, default=0, help="continue an earlier sweep: seeds first .. first + seeds - 1")
+ap.add_argument("--seed-list", default="", help="comma-separated seeds instead of a range (the driver-run slice of the long sweeps: tests/test_gpu_render.py)")
 a = ap.parse_args()
+SEEDS = [int(x) for x in a.seed_list.split(",")] if a.seed_list else list(range(a.first_seed, a.first_seed + a.seeds))
 torch.cuda.init()
 ctx, o = core.Context(0), Oracle()
 f32 = np.float32
@@ -31,7 +33,7 @@ NAMES = {abi.PT_TRAVERSE_MIN_T: "min_t", abi.PT_TRAVERSE_REPLAY: "replay", abi.P
 EXACT_MODES = (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY)
 
 
-for seed in range(a.first_seed, a.first_seed + a.seeds):
+for seed in SEEDS:
     rng = np.random.default_rng(seed)
     tris, mats, sky, scale, images = random_scene(rng, a.sizes)
     try:
