@@ -36,6 +36,25 @@ __global__ __launch_bounds__(256) void k_issue(float* out, int iters, float a, f
                 if (KIND == 9) asm volatile("v_min_u32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
                 if (KIND == 10) asm volatile("v_mov_b32 %0, %1" : "+v"(acc[i]) : "v"(a));
                 if (KIND == 11) asm volatile("v_add_u32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
+                // round 3: the scalar forms of what the triangle test and the packed slab arithmetic are made of
+                if (KIND == 12) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
+                if (KIND == 13) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(b));
+                if (KIND == 14) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(b));
+                if (KIND == 15) asm volatile("v_cmp_ge_f32 vcc, %0, %1" : : "v"(acc[i]), "v"(a) : "vcc");
+                if (KIND == 16) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
+                if (KIND == 17) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+                if (KIND == 18) asm volatile("v_rcp_f32 %0, %0" : "+v"(acc[i]));
+                if (KIND == 19) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pacc[i]) : "v"(pa));
+                if (KIND == 20) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(pacc[i]) : "v"(pa));
+                if (KIND == 21) asm volatile("v_min_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
+                if (KIND == 22) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+                if (KIND == 23) asm volatile("v_and_b32 %0, %0, %1" : "+v"(acc[i]) : "v"(a));
+                if (KIND == 24) asm volatile("v_cmp_ge_f32_e64 %2, %0, %1" : : "v"(acc[i]), "v"(a), "s"(mask));
+                if (KIND == 25) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(acc[i]) : "v"(a));      // two distinct VGPR sources
+                if (KIND == 26) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(acc[i]) : "s"(a));            // one source in an SGPR
+                if (KIND == 27) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(acc[i]) : "v"(a));
+                if (KIND == 28) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+                if (KIND == 29) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(acc[i]) : "v"(a) : "vcc");
             }
         }
     }
@@ -82,6 +101,24 @@ int main() {
     run<9>("v_min_u32", prop.multiProcessorCount, d_out);
     run<10>("v_mov_b32", prop.multiProcessorCount, d_out);
     run<11>("v_add_u32", prop.multiProcessorCount, d_out);
+    run<12>("v_mul_f32", prop.multiProcessorCount, d_out);
+    run<13>("v_add_f32", prop.multiProcessorCount, d_out);
+    run<14>("v_sub_f32", prop.multiProcessorCount, d_out);
+    run<15>("v_cmp_ge_f32 vcc", prop.multiProcessorCount, d_out);
+    run<16>("v_xor_b32", prop.multiProcessorCount, d_out);
+    run<17>("v_or3_b32", prop.multiProcessorCount, d_out);
+    run<18>("v_rcp_f32", prop.multiProcessorCount, d_out);
+    run<19>("v_pk_add_f32", prop.multiProcessorCount, d_out);
+    run<20>("v_pk_fma_f32", prop.multiProcessorCount, d_out);
+    run<21>("v_min_f32", prop.multiProcessorCount, d_out);
+    run<22>("v_min3_f32", prop.multiProcessorCount, d_out);
+    run<23>("v_and_b32", prop.multiProcessorCount, d_out);
+    run<24>("v_cmp_ge_f32_e64 sgpr pair", prop.multiProcessorCount, d_out);
+    run<25>("v_fma_f32 (two distinct VGPR sources)", prop.multiProcessorCount, d_out);
+    run<26>("v_mul_f32 (SGPR source)", prop.multiProcessorCount, d_out);
+    run<27>("v_lshl_add_u32", prop.multiProcessorCount, d_out);
+    run<28>("v_div_fixup_f32", prop.multiProcessorCount, d_out);
+    run<29>("v_div_scale_f32", prop.multiProcessorCount, d_out);
     CHECK(hipFree(d_out));
     return 0;
 }
