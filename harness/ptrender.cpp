@@ -3,9 +3,16 @@
 // scene.camera.samples samples per pixel and displays the tone-mapped buffer in a winit/wgpu window; this
 // harness does the same through include/ptcore.hpp and writes files instead of opening a window:
 //
-//   ptrender scene.toml out [--seed S] [--spp N] [--device D] [--lbvh]
+//   ptrender scene.toml out [--seed S] [--spp N] [--device D] [--chunk K [--stop-after M] [--resume]]
 //     out.png   what the Bgra8Unorm surface holds after renderer.rs:297-309 + shader.wgsl:32-44 (NaN pixels black)
 //     out.pfm   the raw XYZ buffer (main.rs:102-107), little-endian PFM, bottom row first
+//
+// Checkpoint / resume (no counterpart in the reference, which keeps nothing): with --chunk K the render runs as sample ranges
+// [0, K), [K, 2K) ... of PT_RENDER_SUM, the raw sums are added on the host and out.ckpt (header + W*H*4 floats) is rewritten
+// after every range; --resume picks a render up from out.ckpt (same scene size, sample count, seed and chunk or it is
+// refused) and --stop-after M ends the program once M samples are in the checkpoint (exit status 3: incomplete).  Sample s
+// of pixel p draws from stream (seed, p, s) whatever ran before, so a resumed render is the uninterrupted chunked render bit
+// for bit.
 //
 // Test/demo harness, not the product: the product is libptcore.so behind include/ptcore.h.
 #include <chrono>
@@ -85,23 +92,58 @@ void write_pfm(const std::string& path, const std::vector<float>& xyzw, uint32_t
         for (uint32_t x = 0; x < w; ++x) f.write((const char*)&xyzw[4 * ((size_t)y * w + x)], 12);
 }
 
+struct CheckpointHeader {          // out.ckpt: this header, then width * height * 4 floats of raw sums (w = samples so far)
+    char magic[8];                  // "PTCKPT1\0"
+    uint32_t width, height, samples_total, samples_done, chunk, sums_crc;
+    uint64_t seed;
+};
+
+bool save_checkpoint(const std::string& path, const CheckpointHeader& h, const std::vector<float>& sums) {
+    const std::string tmp = path + ".tmp";
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        f.write((const char*)&h, sizeof(h));
+        f.write((const char*)sums.data(), (std::streamsize)(sums.size() * sizeof(float)));
+        if (!f) return false;
+    }
+    return std::rename(tmp.c_str(), path.c_str()) == 0;       // a crash mid-write leaves the previous checkpoint intact
+}
+
+bool load_checkpoint(const std::string& path, CheckpointHeader& h, std::vector<float>& sums, std::string& why) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f || !f.read((char*)&h, sizeof(h))) { why = "cannot read " + path; return false; }
+    if (std::memcmp(h.magic, "PTCKPT1", 8) != 0) { why = path + " is not a ptrender checkpoint"; return false; }
+    if ((uint64_t)h.width * h.height > (1ull << 28)) { why = "checkpoint header is damaged"; return false; }
+    sums.resize((size_t)h.width * h.height * 4);
+    if (!f.read((char*)sums.data(), (std::streamsize)(sums.size() * sizeof(float)))) { why = path + " is truncated"; return false; }
+    if (crc32_of((const uint8_t*)sums.data(), sums.size() * sizeof(float)) != h.sums_crc) { why = path + " fails its checksum"; return false; }
+    return true;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: ptrender scene.toml out_prefix [--seed S] [--spp N] [--device D]\n");
+        std::fprintf(stderr, "usage: ptrender scene.toml out_prefix [--seed S] [--spp N] [--device D] [--chunk K [--stop-after M] [--resume]]\n");
         return 2;
     }
     uint64_t seed = 1;
-    long spp = -1;
+    long spp = -1, chunk_spp = 0, stop_after = -1;
     int device = 0;
-    for (int i = 3; i + 1 < argc; i += 2) {
+    bool resume = false;
+    for (int i = 3; i < argc; ++i) {
         const std::string k = argv[i];
-        if (k == "--seed") seed = std::strtoull(argv[i + 1], nullptr, 10);
-        else if (k == "--spp") spp = std::strtol(argv[i + 1], nullptr, 10);
-        else if (k == "--device") device = std::atoi(argv[i + 1]);
+        if (k == "--resume") { resume = true; continue; }
+        if (i + 1 >= argc) { std::fprintf(stderr, "option %s needs a value\n", k.c_str()); return 2; }
+        const char* v = argv[++i];
+        if (k == "--seed") seed = std::strtoull(v, nullptr, 10);
+        else if (k == "--spp") spp = std::strtol(v, nullptr, 10);
+        else if (k == "--device") device = std::atoi(v);
+        else if (k == "--chunk") chunk_spp = std::strtol(v, nullptr, 10);
+        else if (k == "--stop-after") stop_after = std::strtol(v, nullptr, 10);
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
+    if ((resume || stop_after >= 0) && chunk_spp <= 0) { std::fprintf(stderr, "--resume and --stop-after need --chunk K\n"); return 2; }
     try {
         using namespace pathtracer;
         Device dev(device);
@@ -110,9 +152,48 @@ int main(int argc, char** argv) {
         const auto t1 = std::chrono::steady_clock::now();
         const uint32_t w = scene.camera.resolution[0], h = scene.camera.resolution[1];
         const uint32_t samples = spp > 0 ? (uint32_t)spp : scene.camera.samples;
-        const std::vector<float> xyzw = scene.render(scene.camera, samples, seed);
+        std::vector<float> xyzw;
+        pt_stats st{};
+        if (chunk_spp <= 0) {
+            xyzw = scene.render(scene.camera, samples, seed);
+            st = dev.stats();
+        } else {
+            const std::string ckpt = std::string(argv[2]) + ".ckpt";
+            CheckpointHeader hd{};
+            std::memcpy(hd.magic, "PTCKPT1", 8);
+            hd.width = w; hd.height = h; hd.samples_total = samples; hd.samples_done = 0; hd.chunk = (uint32_t)chunk_spp; hd.seed = seed;
+            std::vector<float> sums((size_t)w * h * 4, 0.0f);
+            if (resume) {
+                CheckpointHeader old{};
+                std::string why;
+                if (!load_checkpoint(ckpt, old, sums, why)) { std::fprintf(stderr, "ptrender: --resume: %s\n", why.c_str()); return 1; }
+                if (old.width != w || old.height != h || old.samples_total != samples || old.seed != seed || old.chunk != hd.chunk ||
+                    old.samples_done > samples || old.samples_done % hd.chunk != 0u) {
+                    std::fprintf(stderr, "ptrender: --resume: %s belongs to another render (%ux%u, %u spp, seed %llu, chunk %u)\n", ckpt.c_str(),
+                                 old.width, old.height, old.samples_total, (unsigned long long)old.seed, old.chunk);
+                    return 1;
+                }
+                hd.samples_done = old.samples_done;
+                std::printf("resuming at sample %u of %u\n", hd.samples_done, samples);
+            }
+            while (hd.samples_done < samples) {
+                if (stop_after >= 0 && hd.samples_done >= (uint32_t)stop_after) {
+                    std::printf("stopped with %u of %u samples in %s\n", hd.samples_done, samples, ckpt.c_str());
+                    return 3;
+                }
+                const uint32_t count = std::min<uint32_t>(hd.chunk, samples - hd.samples_done);
+                const std::vector<float> part = scene.render_range(scene.camera, hd.samples_done, count, samples, seed, PT_RENDER_SUM);
+                const pt_stats cs = dev.stats();
+                st.total_ms += cs.total_ms; st.trace_ms += cs.trace_ms; st.trace_rays += cs.trace_rays; st.paths += cs.paths; st.segments += cs.segments;
+                for (size_t i = 0; i < sums.size(); ++i) sums[i] += part[i];
+                hd.samples_done += count;
+                hd.sums_crc = crc32_of((const uint8_t*)sums.data(), sums.size() * sizeof(float));
+                if (!save_checkpoint(ckpt, hd, sums)) { std::fprintf(stderr, "ptrender: cannot write %s\n", ckpt.c_str()); return 1; }
+            }
+            xyzw = sums;
+            finalize_sums(xyzw);
+        }
         const auto t2 = std::chrono::steady_clock::now();
-        const pt_stats st = dev.stats();
         const Display d = tonemap(dev, xyzw, w, h, 5.0f, 10.0f, PT_TONEMAP_SKIP_NONFINITE);
         write_png(std::string(argv[2]) + ".png", d.bgra8, w, h);
         write_pfm(std::string(argv[2]) + ".pfm", xyzw, w, h);

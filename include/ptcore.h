@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -294,6 +294,12 @@ typedef struct pt_stats {
     double   total_ms;        /* HIP-event time of the whole last call (device side)               */
     uint64_t paths;           /* pt_render: camera paths started                                   */
     uint64_t segments;        /* pt_render: path segments (traversals)                             */
+    /* ABI 3: pt_render's device time by kernel (HIP events around every launch on the library's stream; the rest of total_ms
+     * is clears, the output kernel and gaps between launches).  Zero after calls that are not renders. */
+    double   shade_ms;        /* k_shade: Material::sample + next ray (material.rs:255-297, scene.rs:333-361) */
+    double   sky_ms;          /* k_sky: evaluate_sky (scene.rs:284-305)                            */
+    double   accumulate_ms;   /* k_accumulate: backward fold + CMF + pixel sums (scene.rs:371-373, main.rs:93-107) */
+    double   generate_ms;     /* k_generate: jitter, camera ray, hero wavelength (main.rs:77-89)  */
 } pt_stats;
 int pt_get_stats(const pt_ctx* ctx, pt_stats* out);
 

@@ -85,7 +85,8 @@ class SceneFileInfo(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("trace_ms", C.c_double), ("trace_rays", C.c_uint64), ("trace_launches", C.c_uint32),
-                ("total_ms", C.c_double), ("paths", C.c_uint64), ("segments", C.c_uint64)]
+                ("total_ms", C.c_double), ("paths", C.c_uint64), ("segments", C.c_uint64),
+                ("shade_ms", C.c_double), ("sky_ms", C.c_double), ("accumulate_ms", C.c_double), ("generate_ms", C.c_double)]
 
 
 class SceneInfo(C.Structure):

@@ -522,7 +522,18 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
     PTC_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * sizeof(float4), s));
     PTC_HIP(ctx, hipMemsetAsync(st.counts, 0, 256, s));
     const uint32_t pix_blocks = (npix + PTC_BLOCK - 1) / PTC_BLOCK;
-    size_t n_timed = 0;               // trace launches bracketed by ctx->trace_ev[2i], [2i+1]
+    // per-kernel device time (pt_stats): events from the context's pool bracket every launch group; nothing waits on them
+    // until the render is over
+    enum { T_TRACE = 0, T_SHADE, T_SKY, T_ACCUMULATE, T_GENERATE, T_KINDS };
+    struct Interval { uint32_t kind; size_t begin, end; };
+    std::vector<Interval> timed;
+    size_t n_ev = 0, n_trace_launches = 0;
+    int mark_rc = PT_OK;
+    auto mark = [&]() -> size_t {                         // records the next pooled event on the stream, returns its index
+        const int r = ptc_timed_event(ctx, n_ev);
+        if (r != PT_OK && mark_rc == PT_OK) mark_rc = r;
+        return n_ev++;
+    };
 
     // The path loop runs AHEAD of the host: iteration i's kernels read the live count from the device,
     // the count is copied back asynchronously and only consulted LOOKAHEAD iterations later - to shrink
@@ -544,8 +555,10 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
         st.sample_base[next_slot] = spp_begin + generated;
         st.group[next_slot] = 1u;
         for (uint32_t g = ctx->tune_sample_group; g > 1u; g >>= 1) if (this_spp % g == 0u) { st.group[next_slot] = g; break; }
+        const size_t g0 = mark();
         hipLaunchKernelGGL(k_generate, dim3((P + PTC_BLOCK - 1) / PTC_BLOCK), dim3(PTC_BLOCK), 0, s, st, *cam, seed, next_slot, P, enq % 3u, enq & 1u);
         hipLaunchKernelGGL(k_admit, dim3(1), dim3(64), 0, s, st.counts, enq % 3u, P, n_fifo == 0u ? 1u : 0u);
+        timed.push_back({T_GENERATE, g0, mark()});
         if (n_fifo == 0u) watch_since = enq;
         fifo[n_fifo++] = Pass{next_slot, this_spp, P, enq};
         next_slot = (next_slot + 1u) % slots;
@@ -555,12 +568,17 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
         ctx->stats.segments += P;
     };
     auto fold_front = [&](bool& sky_done) {               // every path of the oldest pass has ended
+        size_t m0 = mark();
         if (!sky_done) {
             const uint32_t sky_blocks = std::min<uint32_t>((st.N + PTC_BLOCK - 1) / PTC_BLOCK, (uint32_t)ctx->n_cus * 16u);
             hipLaunchKernelGGL(k_sky, dim3(sky_blocks), dim3(PTC_BLOCK), 0, s, scene->view, scene->d_sky, st, normalize_sky);
             sky_done = true;
+            const size_t m1 = mark();
+            timed.push_back({T_SKY, m0, m1});
+            m0 = m1;
         }
         hipLaunchKernelGGL(k_accumulate, dim3((npix + PTC_BLOCK / st.group[fifo[0].slot] - 1) / (PTC_BLOCK / st.group[fifo[0].slot])), dim3(PTC_BLOCK), 0, s, st, fifo[0].slot, fifo[0].spp, acc);
+        timed.push_back({T_ACCUMULATE, m0, mark()});
         for (uint32_t i = 1; i < n_fifo; ++i) fifo[i - 1] = fifo[i];
         n_fifo -= 1u;
         watch_since = enq;                                // k_shade launches from now on watch the new front
@@ -568,17 +586,18 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
     if (spp_count != 0u) admit();
     while (n_fifo != 0u) {
         if (enq - harvested <= LOOKAHEAD) {
-            rc = ptc_timed_event(ctx, 2 * n_timed);
-            if (rc != PT_OK) return rc;
+            const size_t t0 = mark();
             rc = ptc_launch_trace(ctx, scene, (const pt_ray*)st.pray[enq & 1u], nullptr, st.queue[enq & 1u], &st.counts[2u * (enq % 3u)],
                                   live_ub, (pt_hit*)st.hits);
             if (rc != PT_OK) return rc;
-            rc = ptc_timed_event(ctx, 2 * n_timed + 1);
-            if (rc != PT_OK) return rc;
-            n_timed += 1;
+            const size_t t1 = mark();
+            timed.push_back({T_TRACE, t0, t1});
+            n_trace_launches += 1;
             const uint32_t shade_blocks = std::max(1u, std::min<uint32_t>((live_ub + PTC_SHADE_SPAN - 1) / PTC_SHADE_SPAN, (uint32_t)ctx->n_cus * ctx->tune_shade_blocks_per_cu));
             hipLaunchKernelGGL(k_shade, dim3(shade_blocks), dim3(PTC_BLOCK), 0, s, scene->view,
                                st, enq & 1u, enq % 3u, seed, fifo[0].slot);
+            timed.push_back({T_SHADE, t1, mark()});
+            if (mark_rc != PT_OK) return mark_rc;
             PTC_HIP(ctx, hipMemcpyAsync(&ctx->h_counters[2u * (enq % RING)], &st.counts[2u * ((enq + 1u) % 3u)], 2 * sizeof(uint32_t),
                                         hipMemcpyDeviceToHost, s));
             PTC_HIP(ctx, hipEventRecord(ctx->count_ev[enq % RING], s));
@@ -610,16 +629,21 @@ static int render_impl(pt_ctx* ctx, const pt_scene* scene, const pt_camera* cam,
     PTC_HIP(ctx, hipEventSynchronize(ctx->ev[3]));
     float total = 0.0f;
     PTC_HIP(ctx, hipEventElapsedTime(&total, ctx->ev[2], ctx->ev[3]));
-    double trace_ms = 0.0;
-    for (size_t i = 0; i < n_timed; ++i) {
+    if (mark_rc != PT_OK) return mark_rc;
+    double by_kind[T_KINDS] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (const Interval& iv : timed) {
         float ms = 0.0f;
-        PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->trace_ev[2 * i], ctx->trace_ev[2 * i + 1]));
-        trace_ms += ms;
+        PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->trace_ev[iv.begin], ctx->trace_ev[iv.end]));
+        by_kind[iv.kind] += ms;
     }
     ctx->stats.total_ms = total;
-    ctx->stats.trace_ms = trace_ms;
+    ctx->stats.trace_ms = by_kind[T_TRACE];
+    ctx->stats.shade_ms = by_kind[T_SHADE];
+    ctx->stats.sky_ms = by_kind[T_SKY];
+    ctx->stats.accumulate_ms = by_kind[T_ACCUMULATE];
+    ctx->stats.generate_ms = by_kind[T_GENERATE];
     ctx->stats.trace_rays = ctx->stats.segments;
-    ctx->stats.trace_launches = (uint32_t)n_timed;
+    ctx->stats.trace_launches = (uint32_t)n_trace_launches;
     return PT_OK;
 }
 

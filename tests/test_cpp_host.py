@@ -68,6 +68,43 @@ def test_ptrender_harness(gpu_ctx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_ptrender_checkpoint_and_resume(tmp_path):
+    """harness/ptrender --chunk K: sample ranges of PT_RENDER_SUM added on the host, a checkpoint (sums + samples done) after every
+    range.  A render stopped after 2 of 6 samples and resumed from its checkpoint is the uninterrupted chunked render bit for
+    bit (sample s of pixel p draws from stream (seed, p, s) whatever ran before); a checkpoint of another render is refused."""
+    root = os.path.dirname(HERE)
+    exe = os.path.join(root, "harness", "ptrender")
+    scene = os.path.join(root, "examples", "cornell", "scene.toml")
+    a, b = str(tmp_path / "whole"), str(tmp_path / "resumed")
+    common = ["--spp", "6", "--seed", "4", "--chunk", "2"]
+    p = subprocess.run([exe, scene, a] + common, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    q = subprocess.run([exe, scene, b] + common + ["--stop-after", "2"], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 3 and "stopped with 2 of 6 samples" in q.stdout and os.path.exists(b + ".ckpt") and not os.path.exists(b + ".pfm")
+    wrong = subprocess.run([exe, scene, b, "--spp", "6", "--seed", "5", "--chunk", "2", "--resume"], capture_output=True, text=True, timeout=300)
+    assert wrong.returncode == 1 and "belongs to another render" in wrong.stderr
+    r = subprocess.run([exe, scene, b] + common + ["--resume"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "resuming at sample 2 of 6" in r.stdout, r.stdout + r.stderr
+    assert open(a + ".pfm", "rb").read() == open(b + ".pfm", "rb").read()
+    assert open(a + ".ckpt", "rb").read() == open(b + ".ckpt", "rb").read()
+    # a damaged checkpoint is refused by its checksum
+    raw = bytearray(open(b + ".ckpt", "rb").read())
+    raw[-5] ^= 0x40
+    open(b + ".ckpt", "wb").write(bytes(raw))
+    bad = subprocess.run([exe, scene, b] + common + ["--resume"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 1 and "checksum" in bad.stderr
+
+
+def test_ptrender_resume_needs_a_chunk_size():
+    root = os.path.dirname(HERE)
+    exe = os.path.join(root, "harness", "ptrender")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "harness"), "ptrender"])
+    p = subprocess.run([exe, "x.toml", "out", "--resume"], capture_output=True, text=True, timeout=30)
+    assert p.returncode == 2 and "--chunk" in p.stderr
+
+
+@pytest.mark.gpu
 def test_ptrender_mgpu_single_rank_equals_ptrender(tmp_path):
     """harness/ptrender_mgpu: the sample-split render from a compiled host - rank processes forked before any GPU call,
     ncclCommInitRank, PT_RENDER_SUM into HBM, ncclAllReduce(ncclFloat, ncclSum), finalize.  With one rank (all this box has)
