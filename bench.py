@@ -269,6 +269,8 @@ def main():
             "trace_Mrays_per_s_rank0": st.trace_rays / max(st.trace_ms, 1e-9) / 1e3,
             "trace_share_of_device_time_rank0": st.trace_ms / max(st.total_ms, 1e-9),
             "trace_launches_rank0": st.trace_launches,
+            "device_ms_by_kernel_rank0": {"total": st.total_ms, "trace": st.trace_ms, "shade": st.shade_ms, "sky": st.sky_ms,
+                                          "accumulate": st.accumulate_ms, "generate": st.generate_ms},
             "allreduce_ms": reduce_ms[0] if use_dist else None, "allreduce_bytes": int(d_img.numel() * 4),
             "finite_pixel_fraction": float(torch.isfinite(img[..., 1]).float().mean()),
         }, d_img
@@ -361,19 +363,52 @@ def main():
                     if not (it.get("tris") == a.tris and it.get("width") == a.width and it.get("height") == a.height and it.get("traversal") == a.traversal):
                         it = {}
                 traffic = it["bytes_per_path_sample"] * a.width * a.height * spp_total if it else None
-                spectral["roofline"] = {
-                    "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "traffic": traffic,
+                # What binds the leg is what binds its dominant kernel, the QUEUED instance of the traversal kernel
+                # (trace_share_of_device_time_rank0 of the render): its VALU issue rate and its vector-L1 lane-load rate against the
+                # same two measured ceilings as the headline, counts per ray from the PMC passes of tools/pmc_integrator.sh over
+                # this scene and frame, rate = the live traversal rate of this render.  SURVEY 8(d)'s HBM figures ride beside it
+                # under their own names (hbm_algorithmic_frac > 1: re-reads served by the caches; it does not bind).
+                qt = it.get("queued_traversal") or {}
+                rays_per_s = spectral["trace_Mrays_per_s_rank0"] * 1e6
+                sceil = {}
+                ipath, gpath = os.path.join(ROOT, "profiles", "issue_roof.json"), os.path.join(ROOT, "profiles", "gather_roof.json")
+                if qt.get("valu_instructions_per_ray") and os.path.exists(ipath):
+                    ij = json.load(open(ipath))
+                    rate = qt["valu_instructions_per_ray"] * rays_per_s
+                    sceil["valu-issue"] = {"bound": "valu-issue", "achieved": rate, "peak": ij["wave_instr_per_s_kernel_mix"], "unit": "wave64-instr/s",
+                                           "frac": rate / ij["wave_instr_per_s_kernel_mix"]}
+                if qt.get("l1_accesses_per_ray") and os.path.exists(gpath):
+                    gj = json.load(open(gpath))
+                    rate = qt["l1_accesses_per_ray"] * rays_per_s / 1e9
+                    sceil["l1-lane-loads"] = {"bound": "l1-lane-loads", "achieved": rate, "peak": gj["l1_lane_loads_per_ns"], "unit": "lane-loads/ns",
+                                              "frac": rate / gj["l1_lane_loads_per_ns"]}
+                if sceil:
+                    top = max(sceil.values(), key=lambda c: c["frac"])
+                    sroof = dict(top)
+                    sroof["other_ceilings"] = {k: v for k, v in sceil.items() if v is not top}
+                else:       # no matching counter profile: nothing on-chip to quote; the HBM figures below are labelled for what they are
+                    sroof = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None}
+                sroof.update({
+                    "kernel": qt.get("kernel", KERNELS[a.traversal] + " (queued)"), "kernel_share_of_device_time": spectral["trace_share_of_device_time_rank0"],
+                    "valu_busy": qt.get("valu_busy"), "active_lanes_per_valu_instruction": qt.get("active_lanes_per_valu_instruction"),
+                    "wave_cycles_waiting_frac": qt.get("wave_cycles_waiting_frac"), "l1_miss_lines_per_ray": qt.get("l1_miss_lines_per_ray"),
+                    "valu_instructions_per_ray": qt.get("valu_instructions_per_ray"), "l1_accesses_per_ray": qt.get("l1_accesses_per_ray"),
+                })
+                spectral["roofline"] = sroof
+                spectral["roofline"].update({
+                    "hbm_algorithmic_GBps": gbps, "hbm_algorithmic_frac": gbps / 8000.0, "traffic": traffic,
                     "hbm_counter_frac": (traffic / spectral["seconds"] / 8e12) if traffic else None,
                     "traffic_bytes_per_path_sample": it.get("bytes_per_path_sample"), "traffic_by_kernel": it.get("kernels"),
                     "traffic_source": it.get("source"),
                     "algorithmic_bytes_per_path_sample": per_path, "segments_per_path": segs / paths,
                     "n_node_per_segment": nodes / segs, "n_tri_per_segment": tris_t / segs,
-                    "note": "SURVEY 8(d)'s figure: algorithmic bytes (reference-rule visits counted by the oracle on sample 0 of every pixel) "
-                            "over wall time. Most of it is node / triangle re-reads that L1 / L2 / Infinity Cache serve; the kernel that "
-                            "dominates (traversal, trace_share_of_device_time_rank0) is bound as the headline roofline says. traffic = counter "
-                            "bytes of all the integrator's kernels for this render (per path-sample x paths; read side doubled, Infinity-Cache "
-                            "hits included), hbm_counter_frac = that over wall time and 8 TB/s",
-                }
+                    "note": "bound / achieved / peak / frac: the on-chip ceiling the leg's dominant kernel (the queued traversal kernel, "
+                            "kernel_share_of_device_time of the render) sits closest to; valu_busy = SQ_ACTIVE_INST_VALU * 4 / (SIMDs * cycles) of "
+                            "that kernel, counters only. hbm_algorithmic_* is SURVEY 8(d)'s figure (reference-rule visits counted by the oracle "
+                            "on sample 0 of every pixel, as bytes over wall time): > 1 of HBM peak because L1 / L2 / Infinity Cache serve the "
+                            "re-reads - it does not bind. traffic = counter bytes of all the integrator's kernels for this render (per "
+                            "path-sample x paths; read side doubled, Infinity-Cache hits included), hbm_counter_frac = that over wall time and 8 TB/s",
+                })
         except Exception as e:  # oracle not built: keep the bench usable, say so
             cpu_baseline = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"unavailable: {type(e).__name__}: {e}"}
     if n_node is None and os.path.exists(golden):
@@ -405,6 +440,9 @@ def main():
                 "frac": rate / ij["wave_instr_per_s_kernel_mix"], "valu_wave_instructions_per_launch": tj["SQ_INSTS_VALU"],
                 "active_lanes_per_valu_instruction": (tj["SQ_THREAD_CYCLES_VALU"] / tj["SQ_INSTS_VALU"]) if tj.get("SQ_THREAD_CYCLES_VALU") else None,
                 "wave_cycles_waiting_frac": (tj["SQ_WAIT_ANY"] / tj["SQ_WAVE_CYCLES"]) if tj.get("SQ_WAVE_CYCLES") else None,
+                # straight from the counters of the profiled launches, no measured ceiling involved: SQ_ACTIVE_INST_VALU counts
+                # quad-cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs, 1024 SIMDs
+                "valu_busy": (tj["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * tj["GRBM_GUI_ACTIVE"] / 8.0)) if tj.get("SQ_ACTIVE_INST_VALU") and tj.get("GRBM_GUI_ACTIVE") else None,
                 "note": "peak = what all 1024 SIMDs issue of this kernel's instruction mix (v_min / v_max / v_cmp / v_cndmask / v_pk_*), "
                         "measured by harness/ptissue (" + ij.get("source", "profiles/") + ")"}
         if tj.get("TCP_TOTAL_CACHE_ACCESSES_sum") and os.path.exists(gpath):

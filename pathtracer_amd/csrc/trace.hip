@@ -48,6 +48,13 @@
 #define PTC_POPS_PER_TRIP 1
 #endif
 #define PTC_FIRST 64u              /* rays of a wave's static first block (one per lane) */
+// -DPTC_MARKERS (analysis builds only, tools/issue_mix.py): comment lines in the assembly at the start of the hot blocks of
+// k_trace_scoped_persistent, so that the VALU opcode mix of each block can be read off `hipcc -S`
+#ifdef PTC_MARKERS
+#define PTC_MARK(name) asm volatile("; PTC_MARK " name)
+#else
+#define PTC_MARK(name) do { } while (0)
+#endif
 
 namespace {
 
@@ -383,6 +390,7 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                 // scene allows it: each lane loads the near planes (lo or hi by the sign of its inverse direction) and the far
                 // planes, and the 24 min / max that pick them drop out.  Uniform base + 32-bit lane offset addressing.
                 if (sc.sign_select_ok && __ballot(!sign_ok) == 0ull) {
+                    PTC_MARK("record_sign");
                     const char* base = reinterpret_cast<const char*>(sc.wide);
                     const uint32_t rec = cur * 128u;
                     const float4 nearx = *reinterpret_cast<const float4*>(base + (rec + near_x));
@@ -394,10 +402,12 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                     const float4 rw = *reinterpret_cast<const float4*>(base + (rec + 96u));
                     ptc_wide_step_sign(r, nearx, neary, nearz, farx, fary, farz, rw, s);
                 } else {
+                    PTC_MARK("record_general");
                     const float4* p = sc.wide + (size_t)cur * 8u;
                     const float4 lox = p[0], loy = p[1], loz = p[2], hix = p[3], hiy = p[4], hiz = p[5], rw = p[6];
                     ptc_wide_step(r, lox, loy, loz, hix, hiy, hiz, rw, s);
                 }
+                PTC_MARK("pushes");
                 // a push opens a scope: a finite m_cur is parked below it (one RESTORE covers all pushes of this visit)
                 if ((s.v0 || s.v1 || s.v2) && m_cur < pt_inf()) { st.push(ring, PTC_RESTORE, __float_as_uint(m_cur)); m_cur = pt_inf(); }
                 if (s.v0) st.push(ring, s.ref0, __float_as_uint(s.e0));
@@ -411,6 +421,7 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
             if (has_ray && (cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
                 const uint32_t tri = cur & PTC_INDEX_MASK;
                 if (tri != skip) {
+                    PTC_MARK("leaf");
                     const float4* tp = sc.tris + (size_t)tri * PTC_TRI_STRIDE;
                     float d, u, v;
                     const DRay r = {rox, roy, roz, rdx, rdy, rdz, rix, riy, riz};
@@ -437,6 +448,7 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                     has_ray = false;
                     sign_ok = true;
                 } else {
+                    PTC_MARK("pop");
                     const uint2 e = st.pop(ring);
                     const float ey = __uint_as_float(e.y);
                     const bool restore = e.x == PTC_RESTORE;                // {RESTORE, the enclosing scope's minimum so far}
@@ -453,6 +465,7 @@ __global__ __launch_bounds__(PTC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 5)
                 }
             }
         }
+        PTC_MARK("loop_end");
     }
 }
 

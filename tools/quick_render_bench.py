@@ -31,6 +31,7 @@ sc = ctx.scene(arr)
 d_img = torch.zeros((a.height, a.width, 4), dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
 ctx.render_dev(sc, a.width, a.height, 0, 1, 1, 1, abi.PT_RENDER_FINAL, d_img.data_ptr())
+rays_total, paths_total = ctx.stats().trace_rays, ctx.stats().paths       # everything this process traces (the counter passes sum over it)
 for r in range(a.reps):
     torch.cuda.synchronize()
     t = time.perf_counter()
@@ -39,6 +40,10 @@ for r in range(a.reps):
     dt = time.perf_counter() - t
     st = ctx.stats()
     print(f"{a.spp} spp in {dt*1e3:.1f} ms -> {a.spp/dt:.1f} spp/s | device {st.total_ms:.1f} ms, trace {st.trace_ms:.1f} ms "
-          f"({st.trace_rays/st.trace_ms/1e3:.0f} Mrays/s, {st.trace_launches} launches), segments/path {st.segments/st.paths:.3f}", flush=True)
+          f"({st.trace_rays/st.trace_ms/1e3:.0f} Mrays/s, {st.trace_launches} launches), segments/path {st.segments/st.paths:.3f} | "
+          f"shade {st.shade_ms:.1f} sky {st.sky_ms:.1f} accumulate {st.accumulate_ms:.1f} generate {st.generate_ms:.1f} ms", flush=True)
+    rays_total += st.trace_rays
+    paths_total += st.paths
+print(f"profile_totals rays {rays_total} paths {paths_total}", flush=True)
 img = d_img.cpu().numpy()
 print("image crc", zlib.crc32(np.nan_to_num(img).tobytes()), "finite", float(np.isfinite(img[..., 1]).mean()))
