@@ -1,4 +1,4 @@
-// scoped_model.cpp — host-side model of the default closest-hit kernel (PT_TRAVERSE_EXACT, trace.hip:
+// scoped_model.cpp — host-side model of the default closest-hit kernel (PT_TRAVERSE_EXACT, trace_kernels.h:
 // k_trace_scoped_persistent).  TEST INFRASTRUCTURE: built into tests/cpp/libscopedmodel.so, loaded by
 // tests/test_scoped_model.py only.
 //
