@@ -318,6 +318,16 @@ void entry_replay_queued() {          // the redo pass of EXACT: ray indices fro
     k_trace_replay_persistent<12, true, false>(a.sc, a.rays, a.start, a.queue, a.count_ptr, a.n, a.out, a.spill, a.total_threads, a.ticket,
                                                a.ticket_next, a.refill, a.ticket_size);
 }
+void entry_scoped_queued() {          // the integrator's form: ray positions from a queue, its length from a device word, start triangle in pad0
+    const Launch& a = g_launch;
+    k_trace_scoped_persistent<12, true>(a.sc, a.rays, nullptr, a.queue, a.count_ptr, a.n, a.out, a.spill, a.total_threads, a.ticket,
+                                        a.ticket_next, a.refill, a.ticket_size, a.redo_list, a.redo_count, a.redo_count_next);
+}
+void entry_replay_redo_of_queued() {
+    const Launch& a = g_launch;
+    k_trace_replay_persistent<12, true, true>(a.sc, a.rays, nullptr, a.queue, a.count_ptr, a.n, a.out, a.spill, a.total_threads, a.ticket,
+                                              a.ticket_next, a.refill, a.ticket_size);
+}
 void entry_mint() {
     const Launch& a = g_launch;
     k_trace_mint_persistent<12, false>(a.sc, a.rays, a.start, nullptr, nullptr, a.n, a.out, a.spill, a.total_threads, a.ticket,
@@ -328,14 +338,18 @@ void entry_mint() {
 
 extern "C" {
 
-// One pt_trace_closest_dev call as trace.hip's launcher makes it, on a grid of `blocks` blocks (a multiple of PTC_SHARDS), waves
+// One pt_trace_closest_dev call (or, with `queue`, one traversal launch of the integrator) as trace.hip's launcher makes it, on a grid of `blocks` blocks (a multiple of PTC_SHARDS), waves
 // scheduled from `seed`.  mode: PT_TRAVERSE_MIN_T / PT_TRAVERSE_EXACT (the scoped kernel, then the frame replay over its redo
 // list on a quarter of the grid) / PT_TRAVERSE_REPLAY.  out[i]: the hits.  stats: [0] fiber switches, [1] rays the scoped kernel
 // listed for the redo pass.  Returns 0, or -1 with a message on stderr (lanes of a wave disagreeing on a collective, a block
 // that does not end).
 int pte_trace(uint32_t mode, const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triangle* tris, uint32_t n_tris,
               const pt_ray* rays, const uint32_t* start, uint32_t n, pt_hit* out, uint32_t blocks, uint32_t refill,
-              uint32_t ticket_size, uint64_t seed, uint64_t stats[2]) {
+              uint32_t ticket_size, uint64_t seed, uint64_t stats[2], const uint32_t* queue, uint32_t n_queue) {
+    // queue != NULL (EXACT only): the kernels trace rays[queue[0 .. n_queue)] (n_queue is handed over through a device word, the
+    // launch's n is the capacity), the start triangle rides in pad0 and hits are written by position; the rest of out[] keeps
+    // the 0xDEADBEEF it was filled with
+    if (queue && mode != PT_TRAVERSE_EXACT) { std::fprintf(stderr, "emu: a queue goes with PT_TRAVERSE_EXACT\n"); return -1; }
     if (blocks == 0 || blocks % PTC_SHARDS != 0) { std::fprintf(stderr, "emu: blocks must be a multiple of %u\n", PTC_SHARDS); return -1; }
     std::vector<float4> wide((size_t)(n_nodes ? n_nodes : 1) * 8, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     std::vector<float4> bin((size_t)(n_nodes ? n_nodes : 1) * 4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
@@ -361,6 +375,8 @@ int pte_trace(uint32_t mode, const pt_bvh_node* nodes, uint32_t n_nodes, const p
     g_launch = Launch{v, reinterpret_cast<const float4*>(rays), start, nullptr, nullptr, n, hits.data(), spill.data(), total_threads,
                       tickets.data(), tickets.data() + 512u, refill, ticket_size, redo_list.data(), tickets.data() + 1024u,
                       tickets.data() + 1024u + 64u};
+    uint32_t queue_count = n_queue;
+    if (queue) { g_launch.queue = queue; g_launch.count_ptr = &queue_count; }
     std::mt19937_64 rng(seed);
     emu::g_switches = 0;
     auto run_grid = [&](void (*entry)(), uint32_t grid) {
@@ -374,7 +390,7 @@ int pte_trace(uint32_t mode, const pt_bvh_node* nodes, uint32_t n_nodes, const p
     };
     stats[1] = 0;
     if (n != 0) {
-        if (!run_grid(mode == PT_TRAVERSE_REPLAY ? entry_replay : mode == PT_TRAVERSE_MIN_T ? entry_mint : entry_scoped, blocks)) return -1;
+        if (!run_grid(queue ? entry_scoped_queued : mode == PT_TRAVERSE_REPLAY ? entry_replay : mode == PT_TRAVERSE_MIN_T ? entry_mint : entry_scoped, blocks)) return -1;
         if (mode == PT_TRAVERSE_EXACT) {
             stats[1] = tickets[1024u];
             if (stats[1] > n) { std::fprintf(stderr, "emu: %llu rays on a redo list of %u\n", (unsigned long long)stats[1], n); return -1; }
@@ -385,7 +401,7 @@ int pte_trace(uint32_t mode, const pt_bvh_node* nodes, uint32_t n_nodes, const p
             g_launch.count_ptr = tickets.data() + 1024u;
             uint32_t grid = blocks / 4u / PTC_SHARDS * PTC_SHARDS;
             if (grid < PTC_SHARDS) grid = PTC_SHARDS;
-            if (!run_grid(entry_replay_queued, grid)) return -1;
+            if (!run_grid(queue ? entry_replay_redo_of_queued : entry_replay_queued, grid)) return -1;
         }
     }
     std::memcpy(out, hits.data(), (size_t)n * sizeof(pt_hit));

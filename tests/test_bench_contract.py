@@ -1,14 +1,18 @@
 """The JSON line bench.py prints (driver contract): checked on the committed output of the last GPU run
-(profiles/r03a_bench.json is what `python bench.py` printed on the MI355X box) and on bench.py's own source."""
+(profiles/r03a_bench.json and r03b_bench.json are what `python bench.py` printed on the MI355X box, r03b on the round's final
+tree) and on bench.py's own source."""
 import json
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_committed_bench_line_has_every_contract_key():
-    j = json.load(open(os.path.join(ROOT, "profiles", "r03a_bench.json")))
+@pytest.mark.parametrize("name", ["r03a_bench.json", "r03b_bench.json"])
+def test_committed_bench_line_has_every_contract_key(name):
+    j = json.load(open(os.path.join(ROOT, "profiles", name)))
     for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "backend", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k

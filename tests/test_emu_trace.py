@@ -27,18 +27,18 @@ def load(name):
     L = C.CDLL(path)
     L.pte_trace.restype = C.c_int
     L.pte_trace.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
-                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]
     return L
 
 
-def run(L, arr, rays, start=None, mode=EXACT, blocks=8, refill=16, ticket=64, seed=1):
+def run(L, arr, rays, start=None, mode=EXACT, blocks=8, refill=16, ticket=64, seed=1, queue=None):
     rays = np.ascontiguousarray(rays, dtype=abi.RAY)
     nodes = arr.nodes if arr.nodes is not None else np.zeros(0, dtype=abi.BVH_NODE)
     out = np.zeros(rays.size, dtype=abi.HIT)
     stats = (C.c_uint64 * 2)()
     st = None if start is None else np.ascontiguousarray(start, dtype=np.uint32)
     rc = L.pte_trace(mode, abi.ptr(nodes), nodes.size, abi.ptr(arr.triangles), arr.triangles.size, abi.ptr(rays), abi.ptr(st),
-                     rays.size, abi.ptr(out), blocks, refill, ticket, seed, stats)
+                     rays.size, abi.ptr(out), blocks, refill, ticket, seed, stats, abi.ptr(queue), 0 if queue is None else queue.size)
     assert rc == 0, "the emulated launch did not end, or its lanes disagreed on a collective (see stderr)"
     return out, int(stats[1])
 
@@ -149,6 +149,28 @@ def test_irregular_rays_and_non_finite_hits(emu, oracle, mode):
     n_redo, n_non_finite = check_underflow(emu, oracle, 12000, mode)
     if mode == EXACT:
         assert n_redo >= n_non_finite > 20
+
+
+def test_the_integrators_queued_form(emu, oracle):
+    """render.hip's traversal launches: ray POSITIONS come from a queue whose length the kernel reads from a device word, the
+    start triangle rides in the ray's pad0, hits are written by position - and the redo pass (irregular rays here: 5 % get an
+    infinite origin component) takes its rays from the scoped kernel's list the same way."""
+    arr = workloads.soup_scene(20_000)
+    prim = core.gen_primary_rays(160, 90)
+    first = oracle.trace(oracle.scene(arr), prim)
+    from tests.golden import fixture_inputs as fi
+    rays, start = fi.bounce_rays(prim, first)
+    rng = np.random.default_rng(3)
+    rays = rays.copy()
+    rays["o"][rng.random(rays.size) < 0.05, 0] = np.inf
+    rays["pad0"] = start.view(np.float32)
+    queue = np.ascontiguousarray(rng.permutation(rays.size)[: rays.size * 2 // 3].astype(np.uint32))
+    want = oracle.trace(oracle.scene(arr), rays, start)
+    got, n_redo = run(emu, arr, rays, None, queue=queue, seed=11)
+    assert n_redo > 100
+    assert got[queue].tobytes() == want[queue].tobytes()
+    rest = np.setdiff1d(np.arange(rays.size), queue)
+    assert (got["tri"][rest] == 0xDEADBEEF).all()
 
 
 def test_min_t_returns_a_minimum_t_hit(emu, oracle):
