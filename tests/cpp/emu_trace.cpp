@@ -303,10 +303,20 @@ struct Launch {
     uint32_t *ticket, *ticket_next, refill, ticket_size, *redo_list, *redo_count, *redo_count_next;
 } g_launch;
 
-void entry_scoped() {
+uint32_t g_ring = 12;      // LDS ring slots per lane of the scoped kernel (PTC_RING: 8, 10, 12 or 16)
+template <int S>
+void scoped() {
     const Launch& a = g_launch;
-    k_trace_scoped_persistent<12, false>(a.sc, a.rays, a.start, nullptr, nullptr, a.n, a.out, a.spill, a.total_threads, a.ticket,
-                                         a.ticket_next, a.refill, a.ticket_size, a.redo_list, a.redo_count, a.redo_count_next);
+    k_trace_scoped_persistent<S, false>(a.sc, a.rays, a.start, nullptr, nullptr, a.n, a.out, a.spill, a.total_threads, a.ticket,
+                                        a.ticket_next, a.refill, a.ticket_size, a.redo_list, a.redo_count, a.redo_count_next);
+}
+void entry_scoped() {
+    switch (g_ring) {
+        case 8: scoped<8>(); break;
+        case 10: scoped<10>(); break;
+        case 16: scoped<16>(); break;
+        default: scoped<12>(); break;
+    }
 }
 void entry_replay() {
     const Launch& a = g_launch;
@@ -345,7 +355,8 @@ extern "C" {
 // that does not end).
 int pte_trace(uint32_t mode, const pt_bvh_node* nodes, uint32_t n_nodes, const pt_triangle* tris, uint32_t n_tris,
               const pt_ray* rays, const uint32_t* start, uint32_t n, pt_hit* out, uint32_t blocks, uint32_t refill,
-              uint32_t ticket_size, uint64_t seed, uint64_t stats[2], const uint32_t* queue, uint32_t n_queue) {
+              uint32_t ticket_size, uint64_t seed, uint64_t stats[2], const uint32_t* queue, uint32_t n_queue, uint32_t ring) {
+    g_ring = ring;
     // queue != NULL (EXACT only): the kernels trace rays[queue[0 .. n_queue)] (n_queue is handed over through a device word, the
     // launch's n is the capacity), the start triangle rides in pad0 and hits are written by position; the rest of out[] keeps
     // the 0xDEADBEEF it was filled with

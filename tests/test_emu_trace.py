@@ -27,18 +27,18 @@ def load(name):
     L = C.CDLL(path)
     L.pte_trace.restype = C.c_int
     L.pte_trace.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
-                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]
+                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32, C.c_uint32]
     return L
 
 
-def run(L, arr, rays, start=None, mode=EXACT, blocks=8, refill=16, ticket=64, seed=1, queue=None):
+def run(L, arr, rays, start=None, mode=EXACT, blocks=8, refill=16, ticket=64, seed=1, queue=None, ring=12):
     rays = np.ascontiguousarray(rays, dtype=abi.RAY)
     nodes = arr.nodes if arr.nodes is not None else np.zeros(0, dtype=abi.BVH_NODE)
     out = np.zeros(rays.size, dtype=abi.HIT)
     stats = (C.c_uint64 * 2)()
     st = None if start is None else np.ascontiguousarray(start, dtype=np.uint32)
     rc = L.pte_trace(mode, abi.ptr(nodes), nodes.size, abi.ptr(arr.triangles), arr.triangles.size, abi.ptr(rays), abi.ptr(st),
-                     rays.size, abi.ptr(out), blocks, refill, ticket, seed, stats, abi.ptr(queue), 0 if queue is None else queue.size)
+                     rays.size, abi.ptr(out), blocks, refill, ticket, seed, stats, abi.ptr(queue), 0 if queue is None else queue.size, ring)
     assert rc == 0, "the emulated launch did not end, or its lanes disagreed on a collective (see stderr)"
     return out, int(stats[1])
 
@@ -101,6 +101,15 @@ def stacked_chain(n):
         nodes[2 * k + 1]["is_leaf"], nodes[2 * k + 1]["shape_index"] = 1, k
     nodes[2 * n - 2]["is_leaf"], nodes[2 * n - 2]["shape_index"] = 1, n - 1
     return abi.SceneArrays(tris, nodes, workloads.soup_scene(8).materials, core.sky_d65(1.0))
+
+
+@pytest.mark.parametrize("ring", [8, 10, 16])
+def test_the_other_ring_sizes(emu, oracle, ring):
+    """PTC_RING picks an instantiation of the scoped kernel with 8, 10 or 16 LDS slots per lane (default 12): same answers, the
+    spill column taking over earlier or later."""
+    check(emu, oracle, stacked_chain(120), core.gen_primary_rays(64, 16), what=f"ring {ring} chain", ring=ring)
+    arr = workloads.soup_scene(5_000)
+    check(emu, oracle, arr, core.gen_primary_rays(96, 54), what=f"ring {ring} soup", ring=ring, seed=ring)
 
 
 @pytest.mark.parametrize("mode", [EXACT, REPLAY, MIN_T])
