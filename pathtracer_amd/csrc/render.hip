@@ -254,10 +254,15 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
                 // The empty asm makes wavelength i+1 "depend" on the result of wavelength i-1: without it the
                 // compiler puts the table rows of all eight wavelengths in flight at once (64+ VGPRs) and the
                 // kernel drops to two waves per SIMD.  Two wavelengths in flight cover the LDS latency.
+#ifdef PTC_EMU      /* the CPU build of this file (tests/cpp/emu_rt.h) has no "v" registers and no need */
+#define PTC_AFTER(next, done) do { } while (0)
+#else
+#define PTC_AFTER(next, done) asm volatile("" : "+v"(next) : "v"(done))
+#endif
 #pragma unroll
                 for (int i = 0; i < PTC_NW; ++i) {
                     weight[i] = ptc::reflectance_at_one(tab, cr, cg, cb, wl[i]);
-                    if (i >= 1 && i + 1 < PTC_NW) asm volatile("" : "+v"(wl[i + 1]) : "v"(weight[i - 1]));
+                    if (i >= 1 && i + 1 < PTC_NW) PTC_AFTER(wl[i + 1], weight[i - 1]);
                 }
                 if (m.emit_kind == PT_EMIT_ABSORBED_D65) {                      // material.rs:183-185
                     has_emit = true;
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(PTC_BLOCK) void k_shade(DevSceneView sc, PassState 
 #pragma unroll
                     for (int i = 0; i < PTC_NW; ++i) {
                         emit[i] = ptc::d65_one(tab, wl[i]) * ptc::reflectance_at_one(tab, ar, ag, ab, wl[i]);
-                        if (i >= 1 && i + 1 < PTC_NW) asm volatile("" : "+v"(wl[i + 1]) : "v"(emit[i - 1]));
+                        if (i >= 1 && i + 1 < PTC_NW) PTC_AFTER(wl[i + 1], emit[i - 1]);
                     }
                 }
                 bool survive = true;

@@ -15,207 +15,13 @@
 // this was.)
 //
 // Blocks run one after the other (a valid schedule of a grid whose blocks only meet at the ticket words).
-#include <ucontext.h>
+#include "emu_rt.h"      // the fibers, the device vocabulary and the scheduler (shared with the library build, libptcore_emu.so)
 
 #include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <limits>
-#include <random>
-#include <vector>
 
 #include "../../pathtracer_amd/csrc/device_types.h"
 #include "../../pathtracer_amd/csrc/trace_step.h"
-
-#if defined(__has_feature)
-#if __has_feature(address_sanitizer)
-#define EMU_ASAN 1
-#include <sanitizer/common_interface_defs.h>
-#endif
-#endif
-
-namespace emu {
-
-struct Dim { uint32_t x, y, z; };
-enum Kind { K_NONE = 0, K_BALLOT, K_FIRST, K_BARRIER };
-
-struct Fiber {
-    ucontext_t ctx;
-    std::vector<char> stack;
-    Dim tid{0, 0, 0};
-    bool done = true;
-    int kind = K_NONE, site = 0;
-    uint64_t arg = 0, result = 0;
-};
-
-Fiber* cur = nullptr;            // the lane that is running
-ucontext_t sched_ctx;
-Dim g_block{0, 1, 1}, g_grid{1, 1, 1};
-void (*g_entry)() = nullptr;
-uint64_t g_switches = 0;
-const char* g_error = nullptr;
-
-const void* sched_stack = nullptr;      // the scheduler's (= the calling thread's) stack, as the sanitizer reports it
-size_t sched_stack_size = 0;
-
-inline void to_scheduler() {
-    Fiber* const me = cur;
-#ifdef EMU_ASAN
-    void* fake = nullptr;
-    __sanitizer_start_switch_fiber(&fake, sched_stack, sched_stack_size);
-#endif
-    swapcontext(&me->ctx, &sched_ctx);
-#ifdef EMU_ASAN
-    __sanitizer_finish_switch_fiber(fake, &sched_stack, &sched_stack_size);
-#endif
-}
-
-inline uint64_t collective(int kind, uint64_t arg, int site) {
-    cur->kind = kind; cur->arg = arg; cur->site = site;
-    to_scheduler();
-    return cur->result;
-}
-
-void trampoline() {
-#ifdef EMU_ASAN
-    __sanitizer_finish_switch_fiber(nullptr, &sched_stack, &sched_stack_size);
-#endif
-    g_entry();
-    cur->done = true;
-    cur->kind = K_NONE;
-    cur->site = 0;
-#ifdef EMU_ASAN
-    __sanitizer_start_switch_fiber(nullptr, sched_stack, sched_stack_size);    // the fiber ends: its fake stack may go
-#endif
-    swapcontext(&cur->ctx, &sched_ctx);
-}
-
-void resume(Fiber& f) {
-    cur = &f;
-    g_switches += 1;
-#ifdef EMU_ASAN
-    void* fake = nullptr;
-    __sanitizer_start_switch_fiber(&fake, f.stack.data(), f.stack.size());
-#endif
-    swapcontext(&sched_ctx, &f.ctx);
-#ifdef EMU_ASAN
-    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
-#endif
-    cur = nullptr;
-}
-
-constexpr uint32_t BLOCK = 256, WAVES = BLOCK / 64;
-std::vector<Fiber> g_fibers;
-
-// one block of `entry`, waves scheduled by `rng`; false (and g_error) when the block's lanes disagree on a collective or
-// `max_steps` wave stretches did not finish it
-bool run_block(void (*entry)(), uint32_t block, uint32_t grid, std::mt19937_64& rng, uint64_t max_steps) {
-    g_entry = entry;
-    g_block = {block, 0, 0};
-    g_grid = {grid, 1, 1};
-    if (g_fibers.size() != BLOCK) {
-        g_fibers.resize(BLOCK);
-        for (auto& f : g_fibers) f.stack.resize(512 * 1024);
-    }
-    for (uint32_t t = 0; t < BLOCK; ++t) {
-        Fiber& f = g_fibers[t];
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack.data();
-        f.ctx.uc_stack.ss_size = f.stack.size();
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, trampoline, 0);
-        f.tid = {t, 0, 0};
-        f.done = false;
-        f.site = 0;
-        f.kind = K_NONE;
-    }
-    bool at_barrier[WAVES] = {false, false, false, false};
-    for (uint64_t step = 0; step < max_steps; ++step) {
-        // waves that can run: lanes left, and not held at a barrier
-        uint32_t live[WAVES], n_live = 0, n_alive = 0, n_waiting = 0;
-        for (uint32_t w = 0; w < WAVES; ++w) {
-            bool any = false;
-            for (uint32_t l = 0; l < 64; ++l) any = any || !g_fibers[w * 64 + l].done;
-            if (!any) continue;
-            n_alive += 1;
-            if (at_barrier[w]) { n_waiting += 1; continue; }
-            live[n_live++] = w;
-        }
-        if (n_alive == 0) return true;
-        if (n_live == 0) {                       // every wave that is left waits at the barrier: release them
-            if (n_waiting != n_alive) { g_error = "barrier bookkeeping"; return false; }
-            for (uint32_t w = 0; w < WAVES; ++w) at_barrier[w] = false;
-            continue;
-        }
-        const uint32_t w = live[rng() % n_live];
-        Fiber* lanes = &g_fibers[w * 64];
-        // resolve the collective the wave's lanes stopped at
-        int kind = K_NONE, site = 0;
-        uint64_t mask = 0, first = 0;
-        bool have_first = false;
-        for (uint32_t l = 0; l < 64; ++l) {
-            if (lanes[l].done) continue;
-            if (kind == K_NONE && lanes[l].kind != K_NONE) { kind = lanes[l].kind; site = lanes[l].site; }
-            if (lanes[l].kind != kind || lanes[l].site != site) {
-                std::fprintf(stderr, "emu: wave %u lane %u at kind %d line %d, an earlier lane at kind %d line %d\n", w, l, lanes[l].kind, lanes[l].site, kind, site);
-                g_error = "lanes of a wave stopped at different collectives";
-                return false;
-            }
-            if (lanes[l].arg) mask |= 1ull << l;
-            if (!have_first) { first = lanes[l].arg; have_first = true; }
-        }
-        for (uint32_t l = 0; l < 64; ++l) lanes[l].result = kind == K_BALLOT ? mask : first;
-        // run every lane to its next collective (or its end)
-        for (uint32_t l = 0; l < 64; ++l) if (!lanes[l].done) resume(lanes[l]);
-        bool barrier = false, other = false;
-        for (uint32_t l = 0; l < 64; ++l) {
-            if (lanes[l].done) continue;
-            if (lanes[l].kind == K_BARRIER) barrier = true; else other = true;
-        }
-        if (barrier && other) { g_error = "some lanes of a wave at a barrier, others not"; return false; }
-        at_barrier[w] = barrier;
-    }
-    g_error = "the block did not finish";
-    return false;
-}
-
-}  // namespace emu
-
-// ---- the device vocabulary the kernels use ------------------------------------------------------------------------------
-#undef __shared__
-#define __shared__ static
-#undef __global__
-#define __global__
-#undef __device__
-#define __device__
-#undef __forceinline__
-#define __forceinline__ inline __attribute__((always_inline))
-#undef __launch_bounds__
-#define __launch_bounds__(...)
-#define threadIdx (emu::cur->tid)
-#define blockIdx (emu::g_block)
-#define gridDim (emu::g_grid)
-#define __ballot(p) emu::collective(emu::K_BALLOT, (p) ? 1u : 0u, __LINE__)
-// (int -> int like the builtin, so that a 64-bit value put together from two of them without care goes wrong here too)
-#define __builtin_amdgcn_readfirstlane(v) ((int)emu::collective(emu::K_FIRST, (uint64_t)(uint32_t)(v), __LINE__))
-#define __syncthreads() ((void)emu::collective(emu::K_BARRIER, 0, __LINE__))
-#define __builtin_amdgcn_s_sleep(n) ((void)0)
-#define __popcll(x) __builtin_popcountll(x)
-#define __popc(x) __builtin_popcount(x)
-static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
-static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
-// (a stretch between two collectives is atomic, so plain read-modify-writes are atomic enough)
-template <typename T> static inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
-template <typename T> static inline T atomicSub(T* p, T v) { const T o = *p; *p = o - v; return o; }
-template <typename T> static inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
-template <typename T> static inline T atomicAnd(T* p, T v) { const T o = *p; *p = o & v; return o; }
-template <typename T> static inline T atomicCAS(T* p, T expect, T v) { const T o = *p; if (o == expect) *p = v; return o; }
-
-#define PTC_EMU 1
-#pragma clang diagnostic ignored "-Wunknown-attributes"
-#pragma clang diagnostic ignored "-Wignored-attributes"
 #include "../../pathtracer_amd/csrc/trace_kernels.h"
 
 namespace {
@@ -388,11 +194,13 @@ int pte_trace(uint32_t mode, const pt_bvh_node* nodes, uint32_t n_nodes, const p
                       tickets.data() + 1024u + 64u};
     uint32_t queue_count = n_queue;
     if (queue) { g_launch.queue = queue; g_launch.count_ptr = &queue_count; }
-    std::mt19937_64 rng(seed);
+    emu::g_rng.seed(seed);
     emu::g_switches = 0;
+    emu::g_error = nullptr;
     auto run_grid = [&](void (*entry)(), uint32_t grid) {
+        emu::g_entry = entry;
         for (uint32_t b = 0; b < grid; ++b) {
-            if (!emu::run_block(entry, b, grid, rng, 1ull << 26)) {
+            if (!emu::run_block(b, grid, PTC_BLOCK, 1ull << 26)) {
                 std::fprintf(stderr, "emu: block %u: %s\n", b, emu::g_error ? emu::g_error : "?");
                 return false;
             }
