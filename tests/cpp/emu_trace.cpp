@@ -14,7 +14,9 @@
 // r03_cross_wave_drain.diff.txt, whose cross-wave protocol it ran under random schedules; that experiment was not kept,
 // this was.)
 //
-// Blocks run one after the other (a valid schedule of a grid whose blocks only meet at the ticket words).
+// Blocks run one after the other (a valid schedule of a grid whose blocks only meet at the ticket words).  The launcher is
+// restated here so that a test can choose grid, refill threshold, ticket size, ring size and schedule per launch; the library
+// build (libptcore_emu.so, tests/test_emu_lib.py) runs trace.hip's own launcher.
 #include "emu_rt.h"      // the fibers, the device vocabulary and the scheduler (shared with the library build, libptcore_emu.so)
 
 #include <cmath>

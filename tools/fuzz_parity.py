@@ -3,7 +3,10 @@
 duplicated triangles, flat and huge/small extents), random rays (axis-parallel directions, origins on box faces,
 zero components), all traversal modes + the device-built BVH, and small renders with random materials
 (dissolve, emitters, nearest-sampled textures with uv outside [0,1], interpolated vertex normals, random Hosek-Wilkie suns, cameras).  Prints one JSON line; every tree (the reference's, and the device-built one read back with pt_scene_get_bvh) is checked against the CPU restatement walking that same tree: EXACT (the default) and REPLAY must agree on every bit; MIN_T may differ only at equal-t ties and, counted separately, where two hits lie within 4 ulp of each other.
-usage: tools/fuzz_parity.py [--seeds N] [--first-seed S] [--seed-list a,b,c] [--rays N]"""
+usage: tools/fuzz_parity.py [--seeds N] [--first-seed S] [--seed-list a,b,c] [--rays N]
+--emu: the same sweep on the CPU against the library compiled for the host (PTCORE_LIB=tests/cpp/libptcore_emu.so PTC_FLATTEN=1
+PTC_WIDE_COLLAPSE=1, optionally the sanitizer build with its runtime preloaded): no torch, no device-built BVH (lbvh.hip is not in that
+build), so keep --sizes and --rays small."""
 import argparse
 import json
 import os
@@ -11,7 +14,6 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
 
 from pathtracer_amd import abi, core, workloads
 from tests.fuzz_scenes import random_rays, random_scene
@@ -23,9 +25,15 @@ ap.add_argument("--sizes", type=int, nargs="*", default=list(__import__("tests.f
 ap.add_argument("--rays", type=int, default=20000)
 ap.add_argument("--first-seed", type=int, default=0, help="continue an earlier sweep: seeds first .. first + seeds - 1")
 ap.add_argument("--seed-list", default="", help="comma-separated seeds instead of a range (the driver-run slice of the long sweeps: tests/test_gpu_render.py)")
+ap.add_argument("--emu", action="store_true", help="CPU build of the library: see the head of this file")
+ap.add_argument("--out", default="", help="also write the JSON line to this file")
 a = ap.parse_args()
 SEEDS = [int(x) for x in a.seed_list.split(",")] if a.seed_list else list(range(a.first_seed, a.first_seed + a.seeds))
-torch.cuda.init()
+if a.emu:
+    assert "emu" in os.path.basename(os.environ.get("PTCORE_LIB", "")), "--emu wants PTCORE_LIB to name the CPU build of the library"
+else:
+    import torch
+    torch.cuda.init()      # (torch first: see tests/conftest.py)
 ctx, o = core.Context(0), Oracle()
 f32 = np.float32
 stats = {"scenes": 0, "rays": 0, "tie_id_mismatches": {}, "t_mismatches": 0, "within_rounding_mismatches": {}, "tie_examples": [], "lbvh_vs_reference_tree": {"rays": 0, "t_differs": 0, "max_ulps": 0, "id_differs_at_equal_t": 0, "hit_in_one_tree_only": 0}, "images": 0, "pixels_differing": {}, "build_errors_agreed": 0, "failures": []}
@@ -53,7 +61,7 @@ for seed in SEEDS:
     want = o.trace(osc, rays)
     start = np.where(rng.random(rays.size) < 0.3, want["tri"], abi.PT_NO_TRIANGLE).astype(np.uint32)
     want_s = o.trace(osc, rays, start)
-    for lbvh in (False, True):
+    for lbvh in ((False,) if a.emu else (False, True)):
         if lbvh and tris.size < 2:
             continue
         sc = ctx.scene(arr, lbvh=lbvh)
@@ -125,5 +133,9 @@ for seed in SEEDS:
             stats["images"] += 1
 stats["ok"] = not stats["failures"] and stats["t_mismatches"] == 0
 stats["failures"] = stats["failures"][:10]
+if a.emu:
+    stats["library"] = os.path.basename(os.environ["PTCORE_LIB"])
 print(json.dumps(stats))
+if a.out:
+    json.dump(stats, open(a.out, "w"), indent=1)
 sys.exit(0 if stats["ok"] else 1)
