@@ -1,5 +1,5 @@
 // emu_rt.h — a CPU stand-in for the parts of HIP that libptcore uses, so that the library's OWN sources (core.hip, trace.hip,
-// render.hip, tonemap.hip: host logic and kernels alike) compile as ordinary C++ and run on the host.  TEST INFRASTRUCTURE:
+// trace_noalloc.hip, render.hip, tonemap.hip, lbvh.hip: host logic and kernels alike) compile as ordinary C++ and run on the host.  TEST INFRASTRUCTURE:
 // force-included (-include) in front of those sources by tests/cpp/Makefile to build tests/cpp/libptcore_emu.so, which the
 // CPU suite loads through the same ctypes binding as the real library (tests/test_emu_lib.py), optionally under the host's
 // address sanitizer.  Nothing here is part of the product.
@@ -227,6 +227,16 @@ inline void launch(uint32_t grid, uint32_t threads, F&& body) {
 #define __builtin_amdgcn_readfirstlane(v) ((int)emu::collective(emu::K_FIRST, (uint64_t)(uint32_t)(v), __LINE__))
 #define __shfl(v, lane) ((uint32_t)emu::collective(emu::K_SHFL, (uint64_t)(uint32_t)(v), __LINE__, (uint64_t)(lane)))
 #define __syncthreads() ((void)emu::collective(emu::K_BARRIER, 0, __LINE__))
+// (the value of lane (own ^ mask), bits preserved for any 4-byte type)
+template <class T> static inline T emu_shfl_xor(T v, int mask, int site) {
+    static_assert(sizeof(T) == 4, "4-byte values only");
+    uint32_t bits; std::memcpy(&bits, &v, 4);
+    const uint32_t r = (uint32_t)emu::collective(emu::K_SHFL, bits, site, (uint64_t)((emu::cur->tid.x & 63u) ^ (uint32_t)mask));
+    T o; std::memcpy(&o, &r, 4); return o;
+}
+#define __shfl_xor(v, mask) emu_shfl_xor((v), (mask), __LINE__)
+#define __clz(x) ((x) ? __builtin_clz((unsigned)(x)) : 32)
+#define __clzll(x) ((x) ? __builtin_clzll((unsigned long long)(x)) : 64)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __popcll(x) __builtin_popcountll(x)
 #define __popc(x) __builtin_popcount(x)

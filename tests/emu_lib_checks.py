@@ -1,8 +1,7 @@
 """Checks run against tests/cpp/libptcore_emu.so - the library's OWN sources (core.hip, trace.hip, trace_noalloc.hip, render.hip,
 tonemap.hip) compiled for the CPU behind tests/cpp/emu_rt.h - through the ordinary ctypes binding.  Not collected by pytest:
 tests/test_emu_lib.py starts this file in a child process with PTCORE_LIB pointing at that library (the binding picks its
-library when it is imported), PTC_FLATTEN=1 PTC_WIDE_COLLAPSE=1 (the host-side node paths: lbvh.hip is not part of the CPU
-build) and, for the sanitizer run, the sanitizer's runtime preloaded.  "Device" pointers are host pointers here.
+library when it is imported) and, for the sanitizer run, the sanitizer's runtime preloaded.  "Device" pointers are host pointers here.
 usage: python -m tests.emu_lib_checks <check> [<check> ...]   (prints `ok <check>` per check)"""
 import ctypes as C
 import os
@@ -147,23 +146,46 @@ def check_tonemap():
     assert (np.abs(bgra8.astype(int) - b2.astype(int)) <= 1).all()
 
 
+def check_lbvh_and_node_paths():
+    """lbvh.hip: the device-side BVH build (read back, the oracle walks that tree), and pt_scene_create's device-side node
+    flattening and wide collapse held byte for byte against the host-side loops (PTC_FLATTEN=2 PTC_WIDE_COLLAPSE=2 make scene
+    creation fail on any difference)"""
+    assert os.environ.get("PTC_FLATTEN") == "2" and os.environ.get("PTC_WIDE_COLLAPSE") == "2"
+    ctx = core.Context(0)
+    rays = core.gen_primary_rays(64, 36)
+    for n in (1, 2, 3, 5, 33, 1000, 4000):
+        arr = workloads.soup_scene(n)
+        sc = ctx.scene(arr)                      # both node paths, compared inside
+        want = O.trace(O.scene(arr), rays)
+        assert ctx.trace(sc, rays).tobytes() == want.tobytes(), n
+        if n >= 2:
+            sc2 = ctx.scene(arr, lbvh=True)
+            tree = sc2.bvh()
+            w2 = O.trace(O.scene(abi.SceneArrays(arr.triangles, tree, arr.materials, arr.sky)), rays)
+            for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_REPLAY):
+                ctx.set_traversal(mode)
+                assert ctx.trace(sc2, rays).tobytes() == w2.tobytes(), (n, mode)
+            ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
+
+
 def check_errors():
-    """what the library refuses: a child index that points backwards, the device-side BVH build (left out of this build)"""
+    """what the library refuses: a child index that points backwards (the device-side validation), a triangle named by two
+    leaves, a sky kind that does not exist"""
     ctx = core.Context(0)
     arr = workloads.soup_scene(50)
-    nodes = arr.nodes.copy()
-    inner = np.flatnonzero(nodes["is_leaf"] == 0)
-    nodes["child_l_index"][inner[1]] = 0
-    try:
-        ctx.scene(abi.SceneArrays(arr.triangles, nodes, arr.materials, arr.sky))
-        raise AssertionError("accepted a backward child index")
-    except core.PtError as e:
-        assert e.code == abi.PT_ERR_INVALID
-    try:
-        ctx.scene(arr, lbvh=True)
-        raise AssertionError("the LBVH build is not in this library")
-    except core.PtError as e:
-        assert e.code == abi.PT_ERR_UNSUPPORTED
+    inner = np.flatnonzero(arr.nodes["is_leaf"] == 0)
+    leaves = np.flatnonzero(arr.nodes["is_leaf"] != 0)
+    for what in ("backward", "twice"):
+        nodes = arr.nodes.copy()
+        if what == "backward":
+            nodes["child_l_index"][inner[1]] = 0
+        else:
+            nodes["shape_index"][leaves[0]] = nodes["shape_index"][leaves[1]]
+        try:
+            ctx.scene(abi.SceneArrays(arr.triangles, nodes, arr.materials, arr.sky))
+            raise AssertionError("accepted: " + what)
+        except core.PtError as e:
+            assert e.code == abi.PT_ERR_INVALID, what
 
 
 CHECKS = {k[len("check_"):]: v for k, v in list(globals().items()) if k.startswith("check_")}

@@ -4,9 +4,8 @@ duplicated triangles, flat and huge/small extents), random rays (axis-parallel d
 zero components), all traversal modes + the device-built BVH, and small renders with random materials
 (dissolve, emitters, nearest-sampled textures with uv outside [0,1], interpolated vertex normals, random Hosek-Wilkie suns, cameras).  Prints one JSON line; every tree (the reference's, and the device-built one read back with pt_scene_get_bvh) is checked against the CPU restatement walking that same tree: EXACT (the default) and REPLAY must agree on every bit; MIN_T may differ only at equal-t ties and, counted separately, where two hits lie within 4 ulp of each other.
 usage: tools/fuzz_parity.py [--seeds N] [--first-seed S] [--seed-list a,b,c] [--rays N]
---emu: the same sweep on the CPU against the library compiled for the host (PTCORE_LIB=tests/cpp/libptcore_emu.so PTC_FLATTEN=1
-PTC_WIDE_COLLAPSE=1, optionally the sanitizer build with its runtime preloaded): no torch, no device-built BVH (lbvh.hip is not in that
-build), so keep --sizes and --rays small."""
+--emu: the same sweep on the CPU against the library compiled for the host (PTCORE_LIB=tests/cpp/libptcore_emu.so, optionally the
+sanitizer build with its runtime preloaded): no torch; keep --sizes and --rays small."""
 import argparse
 import json
 import os
@@ -61,7 +60,7 @@ for seed in SEEDS:
     want = o.trace(osc, rays)
     start = np.where(rng.random(rays.size) < 0.3, want["tri"], abi.PT_NO_TRIANGLE).astype(np.uint32)
     want_s = o.trace(osc, rays, start)
-    for lbvh in ((False,) if a.emu else (False, True)):
+    for lbvh in (False, True):
         if lbvh and tris.size < 2:
             continue
         sc = ctx.scene(arr, lbvh=lbvh)
