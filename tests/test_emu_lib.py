@@ -38,6 +38,52 @@ def test_the_library_compiled_for_the_cpu(check):
     run_checks("libptcore_emu.so", [check])
 
 
+def emu_env(tmp_path):
+    """an environment in which programs linked against libptcore.so find the CPU build under that name"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cpp"), "libptcore_emu.so"])
+    d = tmp_path / "lib"
+    d.mkdir()
+    os.symlink(os.path.join(HERE, "cpp", "libptcore_emu.so"), d / "libptcore.so")
+    return dict(os.environ, LD_LIBRARY_PATH=str(d) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+
+
+def test_cpp_host_program_against_the_cpu_build(tmp_path):
+    """tests/cpp/test_ptcore --all (the reference's triangle and camera tests over the kernels, BVH::build / traverse / render /
+    Scene::load through include/ptcore.hpp against the oracle): the program the GPU suite runs, unchanged, with the CPU build
+    of the library in libptcore.so's place."""
+    exe = os.path.join(HERE, "cpp", "test_ptcore")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(HERE, "cpp"), "test_ptcore"])
+    p = subprocess.run([exe, "--all", str(tmp_path)], env=emu_env(tmp_path), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "all checks passed" in p.stdout and "scene::load" in p.stdout, p.stdout + p.stderr
+
+
+def test_ptrender_checkpoint_and_resume_against_the_cpu_build(tmp_path):
+    """harness/ptrender on a 40 x 40 copy of examples/cornell: a render stopped after 2 of 6 samples and resumed from its
+    checkpoint is the uninterrupted chunked render bit for bit, and the one-call render's PFM equals the library's image."""
+    import shutil
+    import numpy as np
+    exe = os.path.join(ROOT, "harness", "ptrender")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "harness")])
+    scene_dir = tmp_path / "cornell"
+    shutil.copytree(os.path.join(ROOT, "examples", "cornell"), scene_dir)
+    toml = (scene_dir / "scene.toml").read_text().replace("resolution = [512, 512]", "resolution = [40, 40]")
+    assert "[40, 40]" in toml
+    (scene_dir / "scene.toml").write_text(toml)
+    scene = str(scene_dir / "scene.toml")
+    env = emu_env(tmp_path)
+    a, b = str(tmp_path / "whole"), str(tmp_path / "resumed")
+    common = ["--spp", "6", "--seed", "4", "--chunk", "2"]
+    p = subprocess.run([exe, scene, a] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    p = subprocess.run([exe, scene, b] + common + ["--stop-after", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 3, p.stdout + p.stderr
+    p = subprocess.run([exe, scene, b] + common + ["--resume"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert open(a + ".pfm", "rb").read() == open(b + ".pfm", "rb").read()
+
+
 def test_under_the_address_sanitizer():
     rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
     if not rt:
