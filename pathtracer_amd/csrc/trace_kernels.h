@@ -95,30 +95,6 @@ struct LaneStack {
         }
         return e;
     }
-    // the entry pop() would return, without taking it
-    __device__ __forceinline__ uint2 peek(const uint2* __restrict__ ring_) const {
-        const ptc_lds_cu2p ring = (ptc_lds_cu2p)ring_;
-        uint2 e = ptc_lds_get(ring + ptc_umin(idx - PTC_BLOCK, idx + (uint32_t)((S - 1) * PTC_BLOCK)));
-        if (__builtin_expect(cnt == 0u, 0)) e = spill_load(base - 1u);
-        return e;
-    }
-    // ring index of entry j of the LDS part, counted from its oldest (j < cnt)
-    __device__ __forceinline__ uint32_t slot(uint32_t j) const {
-        const uint32_t i = idx + (uint32_t)(S * PTC_BLOCK) - (cnt - j) * PTC_BLOCK;
-        return ptc_umin(i, i - (uint32_t)(S * PTC_BLOCK));
-    }
-    // entry j of the whole stack, counted from its bottom (j < size()): the first `base` of them are in HBM
-    __device__ __forceinline__ uint2 at(const uint2* __restrict__ ring_, uint32_t j) const {
-        const ptc_lds_cu2p ring = (ptc_lds_cu2p)ring_;
-        uint2 e = ptc_lds_get(ring + slot(j < base ? 0u : j - base));
-        if (j < base) e = spill_load(j);
-        return e;
-    }
-    __device__ __forceinline__ void set(uint2* __restrict__ ring_, uint32_t j, uint32_t a, uint32_t b) {
-        const ptc_lds_u2p ring = (ptc_lds_u2p)ring_;
-        if (j < base) spill_store(j, a, b);
-        else ptc_lds_put(ring + slot(j - base), a, b);
-    }
 };
 
 
