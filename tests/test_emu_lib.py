@@ -3,8 +3,8 @@ lbvh.hip - the host logic (scene upload, chunked traces, the pass / slot / look-
 compiled as C++ behind tests/cpp/emu_rt.h: HIP's host API as host memory and synchronous calls, kernels as fibers with the wave
 collectives resolved by a scheduler.  The checks (tests/emu_lib_checks.py) drive it through the SAME ctypes binding as the real
 library, in a child process (the binding picks its library at import), and hold it to the GPU suite's bar: hits and images
-bit-identical to the oracle's.  The last test repeats them under the host's address sanitizer, which sees every "device"
-buffer, LDS array and workspace carve-out.  (hipCUB's sort and scan, which lbvh.hip calls, are std:: algorithms there:
+bit-identical to the oracle's.  The last test repeats them in a build with the host's address and undefined-behaviour
+sanitizers, which see every "device" buffer, LDS array and workspace carve-out, every shift and every index.  (hipCUB's sort and scan, which lbvh.hip calls, are std:: algorithms there:
 tests/cpp/emu_include.)"""
 import glob
 import os
@@ -27,8 +27,9 @@ def run_checks(lib, checks, preload=None, timeout=1500):
     if preload:
         env["LD_PRELOAD"] = (preload + " " + os.environ.get("LD_PRELOAD", "")).strip()
         env["ASAN_OPTIONS"] = "detect_leaks=0"
+        env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
     p = subprocess.run([sys.executable, "-m", "tests.emu_lib_checks"] + checks, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
-    assert p.returncode == 0 and "ERROR: AddressSanitizer" not in p.stderr, p.stderr[-3000:] + p.stdout[-500:]
+    assert p.returncode == 0 and "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-3000:] + p.stdout[-500:]
     for c in checks:
         assert f"ok {c}" in p.stdout, (c, p.stdout[-500:])
 
@@ -84,7 +85,7 @@ def test_ptrender_checkpoint_and_resume_against_the_cpu_build(tmp_path):
     assert open(a + ".pfm", "rb").read() == open(b + ".pfm", "rb").read()
 
 
-def test_under_the_address_sanitizer():
+def test_under_the_address_and_undefined_behaviour_sanitizers():
     rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
     if not rt:
         pytest.skip("no address sanitizer runtime for the ROCm clang")
