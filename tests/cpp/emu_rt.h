@@ -7,7 +7,7 @@
 // Kernels: hipLaunchKernelGGL runs the grid at once, block after block; every lane of a block is a fiber (ucontext); a wave's
 // lanes run one after the other up to their next collective (__ballot, __shfl, readfirstlane, __syncthreads); the scheduler
 // checks that the wave's live lanes all stopped at the same collective, resolves it and picks the next wave of the block at
-// random (seed: PTC_EMU_SEED).  Atomics are plain read-modify-writes (a stretch between two collectives is atomic here),
+// random (seed: PTC_EMU_SEED), and with PTC_EMU_SHUFFLE=1 the blocks of every launch run in a random order.  Atomics are plain read-modify-writes (a stretch between two collectives is atomic here),
 // __shared__ arrays are statics (one block runs at a time).  Streams and events do nothing: every call completes before it
 // returns, so the host logic that runs ahead of the device (render.hip) sees its counters two iterations "late" but correct.
 // What this does not model: memory ordering inside a stretch, concurrency between blocks, timing.
@@ -195,7 +195,16 @@ inline void launch(uint32_t grid, uint32_t threads, F&& body) {
     if (g_error) return;                   // like a sticky HIP error: nothing runs after a failed launch until it was read
     if (grid == 0 || threads == 0 || threads > 1024) { g_error = "bad launch configuration"; return; }
     g_entry = std::forward<F>(body);
-    for (uint32_t b = 0; b < grid; ++b) {
+    // PTC_EMU_SHUFFLE=1: the blocks of a launch run in a random order (the GPU's dispatch order is undefined: nothing may depend on it)
+    static const bool shuffle = [] { const char* v = getenv("PTC_EMU_SHUFFLE"); return v && atoi(v) != 0; }();
+    std::vector<uint32_t> order;
+    if (shuffle) {
+        order.resize(grid);
+        for (uint32_t b = 0; b < grid; ++b) order[b] = b;
+        for (uint32_t b = grid; b > 1; --b) std::swap(order[b - 1], order[g_rng() % b]);
+    }
+    for (uint32_t i = 0; i < grid; ++i) {
+        const uint32_t b = shuffle ? order[i] : i;
         if (!run_block(b, grid, threads, 1ull << 28)) {
             std::fprintf(stderr, "emu: block %u of %u: %s\n", b, grid, g_error ? g_error : "?");
             return;

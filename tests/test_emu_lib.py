@@ -18,12 +18,14 @@ ROOT = os.path.dirname(HERE)
 CHECKS = ["trace", "trace_dev_and_noalloc", "loose_tree", "lbvh_and_node_paths", "render_skies", "render_passes_and_sums", "scene_file", "tonemap", "errors"]
 
 
-def run_checks(lib, checks, preload=None, timeout=1500):
+def run_checks(lib, checks, preload=None, timeout=1500, shuffle=False):
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cpp"), lib])
     # (PTC_FLATTEN / PTC_WIDE_COLLAPSE = 2: every scene is flattened and collapsed by the kernels AND by the host loops, and
     # creation fails unless the two agree on every byte)
     env = dict(os.environ, PTCORE_LIB=os.path.join(HERE, "cpp", lib), PTC_FLATTEN="2", PTC_WIDE_COLLAPSE="2", PTC_PASS_PATHS="65536",
                PYTHONPATH=ROOT)
+    if shuffle:          # the blocks of every launch in a random order (the GPU's dispatch order is undefined)
+        env["PTC_EMU_SHUFFLE"], env["PTC_EMU_SEED"] = "1", "7"
     if preload:
         env["LD_PRELOAD"] = (preload + " " + os.environ.get("LD_PRELOAD", "")).strip()
         env["ASAN_OPTIONS"] = "detect_leaks=0"
@@ -36,7 +38,7 @@ def run_checks(lib, checks, preload=None, timeout=1500):
 
 @pytest.mark.parametrize("check", CHECKS)
 def test_the_library_compiled_for_the_cpu(check):
-    run_checks("libptcore_emu.so", [check])
+    run_checks("libptcore_emu.so", [check], shuffle=True)
 
 
 def emu_env(tmp_path):
