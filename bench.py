@@ -21,6 +21,8 @@ The same JSON line also carries
                 under the REFERENCE's traversal rule, counted by the CPU oracle: re-reads served by L1/L2/Infinity Cache make
                 it exceed 1) and hbm_counter_frac (memory-side bytes from the counters);
   cpu_baseline  the oracle (C++ restatement of the reference algorithm) on this box's host cores;
+  pipelined     the same K steps submitted without a wait between them (pt_trace_closest_dev_submit, --in-flight 2 batches on
+                streams of their own): what a caller that has the next sample's batch ready gets; not the headline;
   spectral      BASELINE configs[2]: spectral path tracing, soup-1M + Hosek-Wilkie sky, 1080p, 64 spp per rank (weak), with
                 its own roofline (algorithmic bytes per path-sample, SURVEY §8d) and cpu_baseline;
   config4       BASELINE configs[3]: the same scene at 3840x2160, --config4-spp samples IN TOTAL (default 1024) split across
@@ -124,6 +126,7 @@ def main():
     ap.add_argument("--spectral-spp", type=int, default=64, help="samples per pixel PER RANK of the spectral leg (config 3: 64; 0 = skip)")
     ap.add_argument("--traversal", choices=["exact", "min_t", "replay"], default="exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight of the `pipelined` leg (pt_trace_closest_dev_submit; 1 = skip the leg, as the profiling scripts do)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' + --one-device rehearses the N>1 code path on a 1-GPU box")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, count them with one all-reduce, print that and stop (no benchmark)")
@@ -216,6 +219,42 @@ def main():
     total_rays = (batch if strong else n * world) * a.steps
     mrays = total_rays / elapsed / 1e6
     kernel_ms_avg = kernel_ms / a.steps
+    # ---- the same K steps without a wait between them (pt_trace_closest_dev_submit / _wait): --in-flight batches queued on
+    # slots of their own, so that the drain of one launch fills with the head of the next.  Reported beside the headline,
+    # which stays the blocking call (one launch alone on the chip: what `roofline` and the rocprofv3 summaries describe).
+    pipelined = None
+    if a.in_flight > 1:
+        try:
+            F = min(a.in_flight, abi.PT_TRACE_SLOTS)
+            d_hits_f = [torch.zeros_like(d_hits) for _ in range(F)]
+            torch.cuda.synchronize()
+
+            def run(steps):
+                for i in range(steps):
+                    slot = i % F
+                    if i >= F:
+                        ctx.trace_dev_wait(slot)              # the slot's hits are complete: its buffer is free again
+                    ctx.trace_dev_submit(scene, d_rays.data_ptr(), 0, n, d_hits_f[slot].data_ptr(), slot)
+                for slot in range(F):
+                    ctx.trace_dev_wait(slot)
+
+            run(max(a.warmup, F))
+            barrier()
+            t0 = time.perf_counter()
+            run(a.steps)
+            barrier()
+            (p_elapsed,) = max_over_ranks(time.perf_counter() - t0)
+            same = all(bool(torch.equal(h, d_hits)) for h in d_hits_f[:min(F, a.steps)])
+            pipelined = {
+                "value": (batch if strong else n * world) * a.steps / p_elapsed / 1e6, "unit": "Mrays/s", "in_flight": F,
+                "ms_per_step": p_elapsed / a.steps * 1e3, "steps": a.steps, "hits_equal_blocking_call": same,
+                "entry_points": "pt_trace_closest_dev_submit / pt_trace_closest_dev_wait",
+                "note": "the same K batches, the next one submitted before the previous one's slowest rays have finished "
+                        "(consecutive samples' batches are independent, main.rs:64-76); throughput of a caller that submits ahead, "
+                        "not the headline",
+            }
+        except Exception as e:
+            pipelined = {"value": None, "unit": "Mrays/s", "error": f"{type(e).__name__}: {e}"}
     # the opt-in global-best traversal on the same batch, for the record (not the headline)
     alt = None
     if a.traversal == "exact":
@@ -489,7 +528,7 @@ def main():
                 "sharding": ("replicated scene, the one batch cut into contiguous chunks per rank, no collective" if strong else
                              "replicated scene, one full batch per rank, no collective"),
             },
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "other_traversal": alt, "spectral": spectral, "config4": config4,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "pipelined": pipelined, "other_traversal": alt, "spectral": spectral, "config4": config4,
         }
         print(json.dumps(out), flush=True)
     if use_dist:

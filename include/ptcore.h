@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 /* ---- status codes ---------------------------------------------------------------------- */
 enum {
@@ -231,7 +231,23 @@ int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_ray
 int pt_trace_closest_dev_noalloc(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
                                  const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out);
 
-/* Traversal flavour used by both calls above and by pt_render.  All walk the caller's BVH (same boxes, same triangles,
+/* pt_trace_closest_dev without the wait: the batches of consecutive samples are independent of one another (the sample loop
+ * `for _ in 0..samples`, main.rs:64-76, carries nothing from one sample's rays to the next), so a caller that has the next
+ * batch ready need not wait for the slowest rays of this one.  pt_trace_closest_dev_submit enqueues the batch on SLOT `slot`
+ * (0 .. PT_TRACE_SLOTS-1) and returns at once; every slot has its own stream and its own traversal scratch (grown on demand
+ * like the context's, so a submit may allocate).  Batches on one slot run in submission order; batches on different slots
+ * may overlap on the GPU - the drain of one launch (a few long rays, most lanes idle) fills with the head of the next.
+ * pt_trace_closest_dev_wait blocks until everything submitted on the slot has completed and fills pt_get_stats (trace_ms =
+ * device time from the first of those kernels' start to the last one's end, trace_rays, trace_launches); waiting on an idle
+ * slot returns at once.  Same kernels, same results bit for bit as pt_trace_closest_dev.  The caller keeps d_rays /
+ * d_start_tri / d_out of a submitted batch alive and untouched until the wait returns; two batches in flight must not share
+ * a d_out.  pt_set_traversal applies to batches submitted after it.  pt_shutdown waits for all slots. */
+#define PT_TRACE_SLOTS 4u
+int pt_trace_closest_dev_submit(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+                                const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out, uint32_t slot);
+int pt_trace_closest_dev_wait(pt_ctx* ctx, uint32_t slot);
+
+/* Traversal flavour used by the calls above and by pt_render. All walk the caller's BVH (same boxes, same triangles,
  * same arithmetic per box and per triangle).
  *   EXACT  (default) returns what traverse_recursive returns (bvh.rs:250-338) on every ray, by construction: the same
  *          leaves are visited in the same order under the same local rule (the far child is entered iff the near child's

@@ -216,6 +216,13 @@ public:
         if (n > 0xF0000000ull) throw Error(PT_ERR_UNSUPPORTED, "Scene::traverse: more than 0xF0000000 rays in one batch");
         dev_->check(pt_trace_closest(dev_->handle(), scene_, rays, start, (uint32_t)n, hits));
     }
+    // Batches already in HBM, without waiting for each: the batches of consecutive samples (main.rs:64-76) are independent, so up
+    // to PT_TRACE_SLOTS of them may be in flight; submit on alternating slots, wait on a slot before reusing its buffers.
+    void traverse_device_submit(const Ray* d_rays, const uint32_t* d_start, size_t n, Hit* d_hits, uint32_t slot) const {
+        if (n > 0xF0000000ull) throw Error(PT_ERR_UNSUPPORTED, "Scene::traverse_device_submit: more than 0xF0000000 rays in one batch");
+        dev_->check(pt_trace_closest_dev_submit(dev_->handle(), scene_, d_rays, d_start, (uint32_t)n, d_hits, slot));
+    }
+    void traverse_device_wait(uint32_t slot) const { dev_->check(pt_trace_closest_dev_wait(dev_->handle(), slot)); }
     // the render closure (main.rs:58-116): X, Y, Z, 1.0 per pixel, index 4*(x + y*W) + c
     std::vector<float> render(const Camera& cam, uint32_t samples, uint64_t seed) const {
         return render_range(cam, 0, samples, samples, seed, PT_RENDER_FINAL);

@@ -29,6 +29,7 @@ PT_TRAVERSE_EXACT = 1
 PT_TRAVERSE_REPLAY = 2
 PT_TRAVERSE_DEFAULT = PT_TRAVERSE_EXACT
 PT_NOALLOC_MAX_RAYS = 4194304
+PT_TRACE_SLOTS = 4
 PT_RENDER_FINAL = 0
 PT_RENDER_SUM = 1
 PT_TONEMAP_SKIP_NONFINITE = 1

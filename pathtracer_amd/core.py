@@ -47,6 +47,8 @@ def lib():
         "pt_trace_closest": (i32, [vp, vp, vp, vp, u32, vp]),
         "pt_trace_closest_dev": (i32, [vp, vp, vp, vp, u32, vp]),
         "pt_trace_closest_dev_noalloc": (i32, [vp, vp, vp, vp, u32, vp]),
+        "pt_trace_closest_dev_submit": (i32, [vp, vp, vp, vp, u32, vp, u32]),
+        "pt_trace_closest_dev_wait": (i32, [vp, u32]),
         "pt_set_traversal": (i32, [vp, u32]),
         "pt_render": (i32, [vp, vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp]),
         "pt_render_dev": (i32, [vp, vp, C.POINTER(abi.Camera), u32, u32, u32, u64, u32, vp]),
@@ -78,6 +80,7 @@ EXPORTS = [
     "pt_scene_get_info", "pt_gen_soup", "pt_gen_primary_rays", "pt_tonemap", "pt_tonemap_dev",
     "pt_scene_file_load", "pt_scene_file_get", "pt_scene_file_free", "pt_scene_create_ex",
     "pt_host_alloc", "pt_host_free", "pt_scene_get_bvh", "pt_trace_closest_dev_noalloc",
+    "pt_trace_closest_dev_submit", "pt_trace_closest_dev_wait",
 ]
 
 
@@ -284,6 +287,14 @@ class Context:
     def trace_dev_noalloc(self, scene, d_rays, d_start, n, d_out):
         self._check(lib().pt_trace_closest_dev_noalloc(self.handle, scene.handle, C.c_void_p(d_rays),
                                                        C.c_void_p(d_start) if d_start else None, int(n), C.c_void_p(d_out)))
+
+    def trace_dev_submit(self, scene, d_rays, d_start, n, d_out, slot=0):
+        """pt_trace_closest_dev without the wait: the batch is queued on `slot` (0 .. abi.PT_TRACE_SLOTS-1)."""
+        self._check(lib().pt_trace_closest_dev_submit(self.handle, scene.handle, C.c_void_p(d_rays),
+                                                      C.c_void_p(d_start) if d_start else None, int(n), C.c_void_p(d_out), int(slot)))
+
+    def trace_dev_wait(self, slot=0):
+        self._check(lib().pt_trace_closest_dev_wait(self.handle, int(slot)))
 
     def render(self, scene, width, height, spp_begin, spp_count, spp_total, seed, mode=abi.PT_RENDER_FINAL,
                sensor_width=36.0, focal_length=50.0):

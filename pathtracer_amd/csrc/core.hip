@@ -128,10 +128,13 @@ extern "C" int pt_init(const int* device_ids, int n, pt_ctx** out) {
     return ptc_guard(nullptr, "pt_init", [&] { return pt_init_body(device_ids, n, out); });
 }
 
+static void ptc_slot_destroy(ptc_trace_slot& sl);
+
 extern "C" void pt_shutdown(pt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& sl : ctx->slots) ptc_slot_destroy(sl);
     if (ctx->spill) (void)hipFree(ctx->spill);
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->io) (void)hipFree(ctx->io);
@@ -227,7 +230,11 @@ int check_texture(pt_ctx* ctx, const pt_texture& t, const pt_scene_desc* d, uint
 
 extern "C" void pt_scene_destroy(pt_ctx* ctx, pt_scene* scene) {
     if (!scene) return;
-    if (ctx) { (void)hipSetDevice(ctx->device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        for (auto& sl : ctx->slots) if (sl.ready) (void)hipStreamSynchronize(sl.stream);      // batches in flight still read the scene
+    }
     for (void* p : scene->allocations) (void)hipFree(p);
     delete scene;
 }
@@ -662,6 +669,94 @@ static int pt_trace_closest_dev_body(pt_ctx* ctx, const pt_scene* scene, const p
 extern "C" int pt_trace_closest_dev(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
                                     const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out) {
     return ptc_guard(ctx, "pt_trace_closest_dev", [&] { return pt_trace_closest_dev_body(ctx, scene, d_rays, d_start_tri, n, d_out); });
+}
+
+// ---- closest hit without the wait: PT_TRACE_SLOTS slots, each a stream and traversal scratch of its own ------------------
+static int ptc_slot_setup(pt_ctx* ctx, ptc_trace_slot& sl) {
+    if (sl.ready) return PT_OK;
+    hipStream_t st = nullptr;
+    PTC_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    uint32_t* tickets = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc((void**)&tickets, PTC_TICKET_BYTES);
+    if (e == hipSuccess) e = hipMemsetAsync(tickets, 0, PTC_TICKET_BYTES, st);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e != hipSuccess) {
+        if (e1) (void)hipEventDestroy(e1);
+        if (e0) (void)hipEventDestroy(e0);
+        (void)hipStreamSynchronize(st);
+        if (tickets) (void)hipFree(tickets);
+        (void)hipStreamDestroy(st);
+        return ptc_hip(ctx, e, "pt_trace_closest_dev_submit: slot set-up");
+    }
+    sl.ready = true;
+    sl.stream = st;
+    sl.ev_begin = e0; sl.ev_end = e1;
+    sl.s = ptc_trace_scratch{};
+    sl.s.tickets = tickets;
+    sl.s.launch_parity = &sl.launch_parity;
+    sl.s.redo_parity = &sl.redo_parity;
+    sl.s.stream = st;
+    sl.s.grow = true;
+    return PT_OK;
+}
+
+static void ptc_slot_destroy(ptc_trace_slot& sl) {
+    if (!sl.ready) return;
+    (void)hipStreamSynchronize(sl.stream);
+    if (sl.s.spill) (void)hipFree(sl.s.spill);
+    if (sl.s.redo) (void)hipFree(sl.s.redo);
+    if (sl.s.tickets) (void)hipFree(sl.s.tickets);
+    if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
+    if (sl.ev_end) (void)hipEventDestroy(sl.ev_end);
+    (void)hipStreamDestroy(sl.stream);
+    sl = ptc_trace_slot{};
+}
+
+static int pt_trace_closest_dev_submit_body(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+                                           const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out, uint32_t slot) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!scene || (n && (!d_rays || !d_out))) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest_dev_submit: NULL argument");
+    if (slot >= PT_TRACE_SLOTS) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest_dev_submit: slot out of range (PT_TRACE_SLOTS)");
+    PTC_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) return PT_OK;
+    ptc_trace_slot& sl = ctx->slots[slot];
+    int rc = ptc_slot_setup(ctx, sl);
+    if (rc != PT_OK) return rc;
+    if (sl.pending == 0u) PTC_HIP(ctx, hipEventRecord(sl.ev_begin, sl.stream));
+    if ((rc = ptc_launch_trace_in(ctx, scene, d_rays, d_start_tri, nullptr, nullptr, n, d_out, &sl.s)) != PT_OK) return rc;
+    PTC_HIP(ctx, hipEventRecord(sl.ev_end, sl.stream));
+    sl.pending += 1u;
+    sl.rays += n;
+    return PT_OK;
+}
+
+extern "C" int pt_trace_closest_dev_submit(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays,
+                                           const uint32_t* d_start_tri, uint32_t n, pt_hit* d_out, uint32_t slot) {
+    return ptc_guard(ctx, "pt_trace_closest_dev_submit", [&] { return pt_trace_closest_dev_submit_body(ctx, scene, d_rays, d_start_tri, n, d_out, slot); });
+}
+
+static int pt_trace_closest_dev_wait_body(pt_ctx* ctx, uint32_t slot) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (slot >= PT_TRACE_SLOTS) return ptc_fail(ctx, PT_ERR_INVALID, "pt_trace_closest_dev_wait: slot out of range (PT_TRACE_SLOTS)");
+    ctx->stats = pt_stats{};
+    ptc_trace_slot& sl = ctx->slots[slot];
+    if (!sl.ready || sl.pending == 0u) return PT_OK;
+    PTC_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t launches = sl.pending;
+    const uint64_t rays = sl.rays;
+    sl.pending = 0u; sl.rays = 0u;          // whatever happens below, the slot starts afresh
+    PTC_HIP(ctx, hipStreamSynchronize(sl.stream));
+    float ms = 0.0f;
+    PTC_HIP(ctx, hipEventElapsedTime(&ms, sl.ev_begin, sl.ev_end));
+    ctx->stats.trace_ms = ms; ctx->stats.total_ms = ms;
+    ctx->stats.trace_rays = rays; ctx->stats.trace_launches = launches;
+    return PT_OK;
+}
+
+extern "C" int pt_trace_closest_dev_wait(pt_ctx* ctx, uint32_t slot) {
+    return ptc_guard(ctx, "pt_trace_closest_dev_wait", [&] { return pt_trace_closest_dev_wait_body(ctx, slot); });
 }
 
 // pinned host memory for callers that want the host-pointer entry points to run at PCIe speed

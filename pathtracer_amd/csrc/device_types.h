@@ -91,6 +91,32 @@ struct pt_scene {
     pt_scene_info info{};
 };
 
+// Where one traversal launch keeps its device-side scratch when that is not the context's own (grown-on-demand) buffers:
+// the allocation-free entry point (trace_noalloc.hip) points these at its file-scope device array, and every slot of
+// pt_trace_closest_dev_submit owns one (grow = true: spill / redo are hipMalloc'd buffers of the slot and grow like the context's).
+struct ptc_trace_scratch {
+    void* spill;        size_t spill_bytes;      // HBM columns of the per-lane stacks
+    uint32_t* tickets;                            // PTC_TICKET_BYTES, zero before the first launch
+    uint32_t* redo;     size_t redo_bytes;       // PT_TRAVERSE_EXACT: 4 bytes per ray of the batch
+    uint32_t max_blocks;                          // grid cap (0: none): bounds the spill columns
+    uint32_t* launch_parity;                      // host-side words that belong to `tickets`
+    uint32_t* redo_parity;
+    hipStream_t stream;                           // the stream the launches go to (nullptr: the context's)
+    bool grow;                                    // spill / redo may be replaced by larger hipMalloc'd buffers (after `stream` has drained)
+};
+
+// One slot of pt_trace_closest_dev_submit / _wait: a stream and traversal scratch of its own, so that batches on different
+// slots can overlap on the GPU.
+struct ptc_trace_slot {
+    bool ready = false;                                   // stream, events and ticket words exist
+    hipStream_t stream = nullptr;
+    ptc_trace_scratch s{};
+    uint32_t launch_parity = 0, redo_parity = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;     // around everything submitted since the last wait
+    uint32_t pending = 0;                                 // batches submitted since the last wait
+    uint64_t rays = 0;
+};
+
 struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -101,6 +127,7 @@ struct pt_ctx {
     std::vector<hipEvent_t> trace_ev;    // pt_render: pairs around every traversal launch (grown on demand)
     uint32_t launch_parity = 0;          // which of the two sets of ticket words the next persistent launch uses
     uint32_t redo_parity = 0;            // which of the two redo counters the next PT_TRAVERSE_EXACT call uses
+    ptc_trace_slot slots[PT_TRACE_SLOTS];   // pt_trace_closest_dev_submit: created on first use
     uint32_t traversal = PT_TRAVERSE_DEFAULT;
     std::string error;
     pt_stats stats{};
@@ -150,17 +177,6 @@ int ptc_timed_event(pt_ctx* ctx, size_t i);
                                      two not required); every grid is a multiple of it (trace.hip, trace_noalloc.hip) */
 #endif
 
-// Where one traversal launch keeps its device-side scratch when that is not the context's own (grown-on-demand) buffers:
-// the allocation-free entry point (trace_noalloc.hip) points these at its file-scope device array.
-struct ptc_trace_scratch {
-    void* spill;        size_t spill_bytes;      // HBM columns of the per-lane stacks
-    uint32_t* tickets;                            // PTC_TICKET_BYTES, zero before the first launch
-    uint32_t* redo;     size_t redo_bytes;       // PT_TRAVERSE_EXACT: 4 bytes per ray of the batch
-    uint32_t max_blocks;                          // grid cap (0: none): bounds the spill columns
-    uint32_t* launch_parity;                      // host-side words that belong to `tickets`
-    uint32_t* redo_parity;
-};
-
 // Entries per thread of the HBM stack columns.  REPLAY: one frame per binary level.  MIN_T: three pending siblings per
 // wide level.  EXACT: at most a RESTORE and three pending entries per wide level (a re-pushed companion replaces two
 // entries by at most two), and its redo pass replays.
@@ -174,7 +190,7 @@ int ptc_noalloc_setup(pt_ctx* ctx);
 
 // launch helpers implemented in trace.hip / render.hip
 int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
-                        const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out, const ptc_trace_scratch* scratch);
+                        const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out, ptc_trace_scratch* scratch);
 int ptc_launch_trace(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
                      const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out);
 

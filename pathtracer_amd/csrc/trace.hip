@@ -47,9 +47,10 @@
 
 // Everything a launch of one traversal flavour needs beyond its arguments: grid, spill columns, ticket words.
 // `scratch` selects where the spill columns, ticket words and redo list live: the context's own buffers (grown on demand),
-// or the caller's (ptc_trace_scratch, trace_noalloc.hip: nothing is allocated then).
+// the fixed array of trace_noalloc.hip (nothing is allocated then), or a slot of pt_trace_closest_dev_submit (its own
+// stream and grown-on-demand buffers, so that batches on different slots can overlap).
 int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays, const uint32_t* d_start,
-                        const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out, const ptc_trace_scratch* scratch) {
+                        const uint32_t* d_queue, const uint32_t* d_count, uint32_t n, pt_hit* d_out, ptc_trace_scratch* scratch) {
     if (n == 0) return PT_OK;
     if (n > 0xF0000000u) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "more than 0xF0000000 rays in one batch");
     const DevSceneView& v = scene->view;
@@ -78,9 +79,18 @@ int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays
     const size_t spill_need = depth * total_threads * sizeof(uint2);
     uint2* spill = nullptr;
     uint32_t *tickets = nullptr, *redo_list = nullptr;
+    hipStream_t stream = (scratch && scratch->stream) ? scratch->stream : ctx->stream;
     if (scratch) {
+        const size_t redo_need = mode == PT_TRAVERSE_EXACT ? (size_t)n * sizeof(uint32_t) : 0u;
+        if (scratch->grow && (spill_need > scratch->spill_bytes || redo_need > scratch->redo_bytes)) {
+            // a slot's own buffers (pt_trace_closest_dev_submit): what is in flight on its stream still uses the old ones
+            int rc = ptc_hip(ctx, hipStreamSynchronize(stream), "hipStreamSynchronize (slot)");
+            if (rc == PT_OK) rc = ptc_reserve(ctx, &scratch->spill, &scratch->spill_bytes, spill_need, "spill (slot)");
+            if (rc == PT_OK) rc = ptc_reserve(ctx, reinterpret_cast<void**>(&scratch->redo), &scratch->redo_bytes, redo_need, "redo list (slot)");
+            if (rc != PT_OK) return rc;
+        }
         if (spill_need > scratch->spill_bytes) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "scene too deep for the fixed traversal scratch");
-        if (mode == PT_TRAVERSE_EXACT && (size_t)n * sizeof(uint32_t) > scratch->redo_bytes) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "batch too large for the fixed traversal scratch");
+        if (redo_need > scratch->redo_bytes) return ptc_fail(ctx, PT_ERR_UNSUPPORTED, "batch too large for the fixed traversal scratch");
         spill = reinterpret_cast<uint2*>(scratch->spill);
         tickets = scratch->tickets;
         redo_list = scratch->redo;
@@ -108,7 +118,7 @@ int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays
     };
     uint32_t *tk = nullptr, *tk_next = nullptr;
     next_tickets(tk, tk_next);
-#define PTC_LAUNCH(kern, qptr, cptr, ...) hipLaunchKernelGGL(kern, grid, block, 0, ctx->stream, v, rays, d_start, qptr, cptr, n, out, spill, total_threads, tk, tk_next, refill, tsize, ##__VA_ARGS__)
+#define PTC_LAUNCH(kern, qptr, cptr, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, v, rays, d_start, qptr, cptr, n, out, spill, total_threads, tk, tk_next, refill, tsize, ##__VA_ARGS__)
     if (mode == PT_TRAVERSE_REPLAY) {
         if (q) PTC_LAUNCH((k_trace_replay_persistent<12, true, true>), d_queue, d_count);
         else PTC_LAUNCH((k_trace_replay_persistent<12, false, false>), d_queue, d_count);

@@ -70,6 +70,35 @@ def check_trace_dev_and_noalloc():
         assert a.tobytes() == want[:n].tobytes() and b.tobytes() == a.tobytes()
 
 
+def check_trace_submit_wait():
+    """pt_trace_closest_dev_submit / _wait: batches queued on several slots (here they run one after the other), different sizes,
+    a slot reused, a wait on an idle slot, refusals"""
+    ctx = core.Context(0)
+    arr = workloads.soup_scene(3000)
+    sc = ctx.scene(arr)
+    rays = np.ascontiguousarray(core.gen_primary_rays(80, 45))
+    want = O.trace(O.scene(arr), rays)
+    outs = []
+    for i, n in enumerate((rays.size, 1000, 64, 2500, 1)):
+        o = np.zeros(n, dtype=abi.HIT)
+        ctx.trace_dev_submit(sc, rays.ctypes.data, None, n, o.ctypes.data, slot=i % abi.PT_TRACE_SLOTS)
+        outs.append(o)
+    for slot in range(abi.PT_TRACE_SLOTS):
+        ctx.trace_dev_wait(slot)
+    assert ctx.stats().trace_launches == 1 and ctx.stats().trace_rays == 2500       # slot 3 held one batch
+    for o in outs:
+        assert o.tobytes() == want[:o.size].tobytes()
+    ctx.trace_dev_wait(2)                                                          # idle: returns at once
+    assert ctx.stats().trace_launches == 0
+    lib = core.lib()
+    o = np.zeros(8, dtype=abi.HIT)
+    rc = lib.pt_trace_closest_dev_submit(ctx.handle, sc.handle, core.C.c_void_p(rays.ctypes.data), None, 8, core.C.c_void_p(o.ctypes.data), abi.PT_TRACE_SLOTS)
+    assert rc == abi.PT_ERR_INVALID and b"slot" in lib.pt_last_error(ctx.handle)
+    assert lib.pt_trace_closest_dev_wait(ctx.handle, 99) == abi.PT_ERR_INVALID
+    assert lib.pt_trace_closest_dev_submit(ctx.handle, sc.handle, None, None, 8, None, 0) == abi.PT_ERR_INVALID
+    ctx.close()
+
+
 def check_loose_tree():
     """a caller's tree whose stored boxes are not the joins: EXACT answers through the frame replay"""
     rng = np.random.default_rng(23)

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, f"declared in ptcore.h but not exported: {missing}"
     assert set(core.EXPORTS) == set(names), "pathtracer_amd.core binds a different set than the header declares"
-    assert core.lib().pt_abi_version() == 3
+    assert core.lib().pt_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header(tmp_path):

@@ -15,7 +15,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-CHECKS = ["trace", "trace_dev_and_noalloc", "loose_tree", "lbvh_and_node_paths", "render_skies", "render_passes_and_sums", "scene_file", "tonemap", "errors"]
+CHECKS = ["trace", "trace_dev_and_noalloc", "trace_submit_wait", "loose_tree", "lbvh_and_node_paths", "render_skies", "render_passes_and_sums", "scene_file", "tonemap", "errors"]
 
 
 def run_checks(lib, checks, preload=None, timeout=1500, shuffle=False):

@@ -170,3 +170,77 @@ def test_host_pointer_path_is_chunked_and_accepts_pinned_memory(oracle, gpu_ctx)
     assert p_out.array.tobytes() == want_s.tobytes()
     for p in (p_rays, p_start, p_out):
         p.close()
+
+
+def test_submit_and_wait_equal_the_blocking_call(gpu_ctx):
+    """pt_trace_closest_dev_submit / _wait (ptcore.h): batches in flight on several slots, and several on one slot, give
+    pt_trace_closest_dev's hits bit for bit in every traversal mode - different sizes, with and without start triangles,
+    irregular rays (the redo path of EXACT runs on the slot's own stream and list); slots are reused, a slot's scratch grows
+    when a larger batch follows a small one, an idle slot's wait returns at once, bad slots are refused."""
+    import torch
+    lib = core.lib()
+    arr = workloads.soup_scene(200_000)
+    sc = gpu_ctx.scene(arr)
+    rays = core.gen_primary_rays(960, 540)
+    rays["d"][5] = 0.0
+    rays["o"][6, 0] = np.inf
+    n = rays.size
+    rng = np.random.default_rng(3)
+    start = np.where(rng.random(n) < 0.3, rng.integers(0, arr.triangles.size, n), abi.PT_NO_TRIANGLE).astype(np.uint32)
+    d_rays = torch.from_numpy(rays.view(np.uint8).reshape(n, -1).copy()).cuda()
+    d_start = torch.from_numpy(start.view(np.int32)).cuda()
+    # (size, offset into the batch, with start triangles); small first, so that slot 0's buffers grow under way
+    jobs = [(4096, 0, False), (n, 0, False), (n // 3, 1000, True), (257, 77, False), (n // 2, n // 2, True), (n, 0, True), (1, 9, False)]
+    try:
+        for mode in (abi.PT_TRAVERSE_EXACT, abi.PT_TRAVERSE_MIN_T, abi.PT_TRAVERSE_REPLAY):
+            gpu_ctx.set_traversal(mode)
+            want, got = [], []
+            for m, off, st in jobs:
+                w = torch.zeros((m, 4), dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                gpu_ctx.trace_dev(sc, d_rays.data_ptr() + 32 * off, d_start.data_ptr() + 4 * off if st else 0, m, w.data_ptr())
+                want.append(w)
+                got.append(torch.zeros((m, 4), dtype=torch.int32, device="cuda"))
+            torch.cuda.synchronize()
+            for i, (m, off, st) in enumerate(jobs):          # slots 0, 1, 2, 0, 1, 2, 0: up to three batches queued on one slot
+                gpu_ctx.trace_dev_submit(sc, d_rays.data_ptr() + 32 * off, d_start.data_ptr() + 4 * off if st else 0, m, got[i].data_ptr(), slot=i % 3)
+            total = 0
+            for slot in range(3):
+                gpu_ctx.trace_dev_wait(slot)
+                s = gpu_ctx.stats()
+                assert s.trace_launches == len(jobs[slot::3]) and s.trace_rays == sum(j[0] for j in jobs[slot::3]) and s.trace_ms > 0.0
+                total += s.trace_rays
+            assert total == sum(j[0] for j in jobs)
+            for i in range(len(jobs)):
+                assert torch.equal(got[i], want[i]), (mode, i)
+            assert int((want[1][:, 0] != -1).sum()) > n // 2
+            gpu_ctx.trace_dev_wait(3)                          # never used: nothing to wait for
+            assert gpu_ctx.stats().trace_launches == 0
+    finally:
+        gpu_ctx.set_traversal(abi.PT_TRAVERSE_DEFAULT)
+    vp = core.C.c_void_p
+    assert lib.pt_trace_closest_dev_submit(gpu_ctx.handle, sc.handle, vp(d_rays.data_ptr()), None, 8, vp(got[0].data_ptr()), abi.PT_TRACE_SLOTS) == abi.PT_ERR_INVALID
+    assert b"slot" in lib.pt_last_error(gpu_ctx.handle)
+    assert lib.pt_trace_closest_dev_wait(gpu_ctx.handle, abi.PT_TRACE_SLOTS) == abi.PT_ERR_INVALID
+    assert lib.pt_trace_closest_dev_submit(gpu_ctx.handle, sc.handle, None, None, 8, None, 0) == abi.PT_ERR_INVALID
+    assert lib.pt_trace_closest_dev_submit(gpu_ctx.handle, sc.handle, None, None, 0, None, 0) == abi.PT_OK
+
+
+def test_a_context_with_batches_in_flight_shuts_down_cleanly():
+    """pt_shutdown waits for every slot (the hits of a submitted batch are complete afterwards)."""
+    import torch
+    ctx = core.Context(0)
+    arr = workloads.soup_scene(50_000)
+    sc = ctx.scene(arr)
+    rays = core.gen_primary_rays(640, 360)
+    n = rays.size
+    d_rays = torch.from_numpy(rays.view(np.uint8).reshape(n, -1).copy()).cuda()
+    want = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    got = [torch.zeros((n, 4), dtype=torch.int32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    ctx.trace_dev(sc, d_rays.data_ptr(), 0, n, want.data_ptr())
+    for i in range(2):
+        ctx.trace_dev_submit(sc, d_rays.data_ptr(), 0, n, got[i].data_ptr(), slot=i)
+    ctx.close()
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], want) and torch.equal(got[1], want)

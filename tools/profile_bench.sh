@@ -10,7 +10,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 20 --warmup 2 --no-cpu-baseline --config4-spp 0 $*"
+# (--in-flight 1: no pipelined leg, so that every launch of the traversal kernel in the trace is one launch alone on the chip)
+ARGS="--steps 20 --warmup 2 --no-cpu-baseline --config4-spp 0 --in-flight 1 $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- python3 $R/bench.py $ARGS --spectral-spp 16 > $OUT/trace.log 2>&1 || { echo "kernel-trace failed"; tail -5 $OUT/trace.log; exit 1; }
 PASSES=(
  "FETCH_SIZE"
