@@ -112,7 +112,9 @@ static int pt_init_body(const int* device_ids, int n, pt_ctx** out) {
     ctx->tune_ring = env_u32("PTC_RING", ctx->tune_ring);
     ctx->tune_flatten = std::min(2u, env_u32("PTC_FLATTEN", ctx->tune_flatten));
     ctx->tune_trust_joins = env_u32("PTC_TRUST_JOINS", 0u) != 0u;
-    ctx->tune_host_chunk = std::max(1u << 12, std::min(1u << 28, env_u32("PTC_HOST_CHUNK", ctx->tune_host_chunk)));
+    ctx->tune_host_chunk = env_u32("PTC_HOST_CHUNK", 0u);
+    if (ctx->tune_host_chunk) ctx->tune_host_chunk = std::max(1u << 12, std::min(1u << 28, ctx->tune_host_chunk));
+    ctx->tune_host_slots = std::max(1u, std::min(PT_TRACE_SLOTS, env_u32("PTC_HOST_SLOTS", ctx->tune_host_slots)));
     ctx->tune_pass_paths = std::max(1u << 16, std::min(192u << 20, env_u32("PTC_PASS_PATHS", ctx->tune_pass_paths)));
     ctx->tune_work_limit = (size_t)env_u32("PTC_WORK_LIMIT_MB", 0u) << 20;
     ctx->tune_sample_group = std::max(1u, std::min(64u, env_u32("PTC_SAMPLE_GROUP", ctx->tune_sample_group)));
@@ -769,6 +771,8 @@ extern "C" int pt_host_alloc(size_t bytes, void** out) {
 }
 extern "C" void pt_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+static int ptc_slot_setup(pt_ctx* ctx, ptc_trace_slot& sl);
+
 static int trace_closest_host(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays, const uint32_t* start_tri, uint32_t n, pt_hit* out) {
     const size_t rb = (size_t)n * sizeof(pt_ray), sb = (size_t)n * sizeof(uint32_t), hb = (size_t)n * sizeof(pt_hit);
     const size_t sb_pad = (sb + 255) & ~(size_t)255;
@@ -778,40 +782,64 @@ static int trace_closest_host(pt_ctx* ctx, const pt_scene* scene, const pt_ray* 
     pt_ray* d_rays = (pt_ray*)base;
     uint32_t* d_start = (uint32_t*)(base + rb);
     pt_hit* d_out = (pt_hit*)(base + rb + sb_pad);
-    // Chunks of 1 Mi rays (PTC_HOST_CHUNK): the upload of chunk c+1, the kernel of chunk c and the download of chunk c-1 overlap
-    // (three streams chained by events).  With pinned host buffers (pt_host_alloc) every copy is asynchronous and the
-    // call runs at the speed of the slower PCIe direction; pageable buffers make the runtime stage each copy, which
-    // serialises them on the calling thread (the kernels still overlap).
-    const uint32_t CHUNK = ctx->tune_host_chunk;
+    // Chunks of PTC_HOST_CHUNK rays: the upload of chunk c+1, the kernel of chunk c and the download of chunk c-1 overlap
+    // (streams chained by events).  The kernels of consecutive chunks go to alternating trace slots (PTC_HOST_SLOTS of them, the
+    // streams and scratch of pt_trace_closest_dev_submit), so that the drain of one chunk's launch fills with the head of the
+    // next.  With pinned host buffers (pt_host_alloc) every copy is asynchronous and the call runs at the speed of the slower
+    // PCIe direction; pageable buffers make the runtime stage each copy, which serialises them on the calling thread (the
+    // kernels still overlap).
+    // (chunk size: PTC_HOST_CHUNK when set; else 512 Ki rays when the caller's rays are in pinned memory - the copies are DMA, smaller
+    // chunks start the first kernel sooner and two slots hide their launches' drains: 2.60 -> 2.12 ms per 2 M rays - and 1 Mi rays
+    // for pageable memory, where every chunk costs a staged copy on the calling thread)
+    uint32_t CHUNK = ctx->tune_host_chunk;
+    if (CHUNK == 0u) {
+        hipPointerAttribute_t at{};
+        const bool pinned = hipPointerGetAttributes(&at, rays) == hipSuccess && at.type == hipMemoryTypeHost;
+        (void)hipGetLastError();          // an unregistered pointer is reported as an error by some runtimes: not ours to keep
+        CHUNK = pinned ? (1u << 19) : (1u << 20);
+    }
     const uint32_t n_chunks = (n + CHUNK - 1u) / CHUNK;
+    const uint32_t n_slots = std::min<uint32_t>(std::min<uint32_t>(ctx->tune_host_slots, PT_TRACE_SLOTS), n_chunks);
+    for (uint32_t k = 0; k < n_slots; ++k)
+        if ((rc = ptc_slot_setup(ctx, ctx->slots[k])) != PT_OK) return rc;
+    // per chunk: {rays uploaded, hits ready} without timing, {kernel start, kernel end} with
     while (ctx->pipe_ev.size() < 2u * (size_t)n_chunks) {
         hipEvent_t e = nullptr;
         PTC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->pipe_ev.push_back(e);
     }
+    while (ctx->trace_ev.size() < 2u * (size_t)n_chunks) {
+        hipEvent_t e = nullptr;
+        PTC_HIP(ctx, hipEventCreate(&e));
+        ctx->trace_ev.push_back(e);
+    }
     ctx->stats = pt_stats{};
     PTC_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    for (uint32_t k = 0; k < n_slots; ++k) PTC_HIP(ctx, hipStreamWaitEvent(ctx->slots[k].stream, ctx->ev[0], 0));
     for (uint32_t c = 0; c < n_chunks; ++c) {
         const uint32_t b = c * CHUNK, m = std::min(CHUNK, n - b);
+        ptc_trace_slot& sl = ctx->slots[c % n_slots];
         PTC_HIP(ctx, hipMemcpyAsync(d_rays + b, rays + b, (size_t)m * sizeof(pt_ray), hipMemcpyHostToDevice, ctx->copy_in));
         if (start_tri) PTC_HIP(ctx, hipMemcpyAsync(d_start + b, start_tri + b, (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->copy_in));
         PTC_HIP(ctx, hipEventRecord(ctx->pipe_ev[2u * c], ctx->copy_in));
-        PTC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_ev[2u * c], 0));
-        if ((rc = ptc_timed_event(ctx, 2u * c)) != PT_OK) return rc;
-        if ((rc = ptc_launch_trace(ctx, scene, d_rays + b, start_tri ? d_start + b : nullptr, nullptr, nullptr, m, d_out + b)) != PT_OK) return rc;
-        if ((rc = ptc_timed_event(ctx, 2u * c + 1u)) != PT_OK) return rc;
-        PTC_HIP(ctx, hipEventRecord(ctx->pipe_ev[2u * c + 1u], ctx->stream));
+        PTC_HIP(ctx, hipStreamWaitEvent(sl.stream, ctx->pipe_ev[2u * c], 0));
+        PTC_HIP(ctx, hipEventRecord(ctx->trace_ev[2u * c], sl.stream));
+        if ((rc = ptc_launch_trace_in(ctx, scene, d_rays + b, start_tri ? d_start + b : nullptr, nullptr, nullptr, m, d_out + b, &sl.s)) != PT_OK) return rc;
+        PTC_HIP(ctx, hipEventRecord(ctx->trace_ev[2u * c + 1u], sl.stream));
+        PTC_HIP(ctx, hipEventRecord(ctx->pipe_ev[2u * c + 1u], sl.stream));
         PTC_HIP(ctx, hipStreamWaitEvent(ctx->copy_out, ctx->pipe_ev[2u * c + 1u], 0));
         PTC_HIP(ctx, hipMemcpyAsync(out + b, d_out + b, (size_t)m * sizeof(pt_hit), hipMemcpyDeviceToHost, ctx->copy_out));
     }
+    for (uint32_t c = n_chunks - n_slots; c < n_chunks; ++c) PTC_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_ev[2u * c + 1u], 0));
     PTC_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     PTC_HIP(ctx, hipStreamSynchronize(ctx->copy_out));
     PTC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double trace_ms = 0.0;
-    for (uint32_t c = 0; c < n_chunks; ++c) {
+    // kernels of different slots overlap: their time is first start to last end
+    float trace_ms = 0.0f;
+    for (uint32_t c = n_chunks - n_slots; c < n_chunks; ++c) {
         float ms = 0.0f;
-        PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->trace_ev[2u * c], ctx->trace_ev[2u * c + 1u]));
-        trace_ms += ms;
+        PTC_HIP(ctx, hipEventElapsedTime(&ms, ctx->trace_ev[0], ctx->trace_ev[2u * c + 1u]));
+        trace_ms = std::max(trace_ms, ms);
     }
     float total = 0.0f;
     PTC_HIP(ctx, hipEventElapsedTime(&total, ctx->ev[0], ctx->ev[1]));
@@ -828,7 +856,9 @@ static int pt_trace_closest_body(pt_ctx* ctx, const pt_scene* scene, const pt_ra
     PTC_HIP(ctx, hipSetDevice(ctx->device));
     const int rc = trace_closest_host(ctx, scene, rays, start_tri, n, out);
     if (rc != PT_OK) {      // leave nothing in flight that still reads or writes the caller's buffers
-        (void)hipStreamSynchronize(ctx->copy_in); (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->copy_out);
+        (void)hipStreamSynchronize(ctx->copy_in); (void)hipStreamSynchronize(ctx->stream);
+        for (auto& sl : ctx->slots) if (sl.ready) (void)hipStreamSynchronize(sl.stream);
+        (void)hipStreamSynchronize(ctx->copy_out);
     }
     return rc;
 }

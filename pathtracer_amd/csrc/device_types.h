@@ -149,7 +149,8 @@ struct pt_ctx {
     uint32_t tune_ticket = 64;           // rays a wave reserves per ticket atomic (after its static first block of 64)
     uint32_t tune_shade_blocks_per_cu = 256; // k_shade grid cap (blocks loop over the queue beyond it; a looping block scatters its spans over the next queue, which the traversal of that queue pays for)
     uint32_t tune_ring = 12;             // LDS ring slots per lane of the EXACT traversal kernel (8, 12 or 16)
-    uint32_t tune_host_chunk = 1u << 20;   // pt_trace_closest: rays per pipelined chunk
+    uint32_t tune_host_chunk = 0;          // pt_trace_closest: rays per pipelined chunk (0: by the kind of host memory, core.hip)
+    uint32_t tune_host_slots = 2;          // pt_trace_closest: trace slots the chunks' kernels alternate between (1: one stream, no overlap of kernels)
     uint32_t tune_pass_paths = 128u << 20; // pt_render: paths in flight (~1.15 KiB of HBM each)
     size_t   tune_work_limit = 0;          // pt_render: workspace bytes it may reserve (0: what hipMalloc gives); beyond it the pass is halved, as when HBM is short
     uint32_t tune_sample_group = 16;       // pt_render: samples of one pixel side by side in the path ids (power of two dividing the pass's samples)

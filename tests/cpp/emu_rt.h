@@ -298,6 +298,7 @@ inline hipError_t props(hipDeviceProp_t* p) {
 #define hipFree(p) emu::release((void*)(p))
 #define hipHostMalloc(p, n, flags) emu::malloc_t((p), (n))
 #define hipHostFree(p) emu::release((void*)(p))
+#define hipPointerGetAttributes(a, p) ((a)->type = hipMemoryTypeUnregistered, hipSuccess)
 #define hipMemcpy(d, s, n, kind) emu::copy((d), (s), (n))
 #define hipMemcpyAsync(d, s, n, kind, stream) emu::copy((d), (s), (n))
 #define hipMemset(d, v, n) emu::set((d), (v), (n))

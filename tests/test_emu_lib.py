@@ -21,8 +21,9 @@ CHECKS = ["trace", "trace_dev_and_noalloc", "trace_submit_wait", "loose_tree", "
 def run_checks(lib, checks, preload=None, timeout=1500, shuffle=False):
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cpp"), lib])
     # (PTC_FLATTEN / PTC_WIDE_COLLAPSE = 2: every scene is flattened and collapsed by the kernels AND by the host loops, and
-    # creation fails unless the two agree on every byte)
-    env = dict(os.environ, PTCORE_LIB=os.path.join(HERE, "cpp", lib), PTC_FLATTEN="2", PTC_WIDE_COLLAPSE="2", PTC_PASS_PATHS="65536",
+    # creation fails unless the two agree on every byte; PTC_HOST_CHUNK: pt_trace_closest cuts its batches into several chunks, whose
+    # launches alternate between two trace slots)
+    env = dict(os.environ, PTCORE_LIB=os.path.join(HERE, "cpp", lib), PTC_FLATTEN="2", PTC_WIDE_COLLAPSE="2", PTC_PASS_PATHS="65536", PTC_HOST_CHUNK="4096",
                PYTHONPATH=ROOT)
     if shuffle:          # the blocks of every launch in a random order (the GPU's dispatch order is undefined)
         env["PTC_EMU_SHUFFLE"], env["PTC_EMU_SEED"] = "1", "7"

@@ -150,8 +150,9 @@ def test_batch_beyond_2_to_31_rays(gpu_ctx):
 
 
 def test_host_pointer_path_is_chunked_and_accepts_pinned_memory(oracle, gpu_ctx):
-    """pt_trace_closest pipelines chunks of 1 Mi rays: a batch of several chunks with a ragged tail, with and
-    without start triangles, from pageable and from pinned (pt_host_alloc) buffers."""
+    """pt_trace_closest pipelines chunks (1 Mi rays from pageable memory, 512 Ki from pinned; their kernels alternate between
+    two trace slots): a batch of several chunks with a ragged tail, with and without start triangles, from pageable and from
+    pinned (pt_host_alloc) buffers."""
     arr = workloads.soup_scene(20_000)
     sc, osc = gpu_ctx.scene(arr), oracle.scene(arr)
     base = core.gen_primary_rays(1280, 720)                       # 921 600 rays
@@ -168,6 +169,8 @@ def test_host_pointer_path_is_chunked_and_accepts_pinned_memory(oracle, gpu_ctx)
     p_start.array[:] = start
     gpu_ctx.trace(sc, p_rays.array, p_start.array, out=p_out.array)
     assert p_out.array.tobytes() == want_s.tobytes()
+    assert gpu_ctx.stats().trace_launches == 5 and gpu_ctx.stats().trace_rays == rays.size       # 4 chunks of 512 Ki + the tail
+    assert 0.0 < gpu_ctx.stats().trace_ms <= gpu_ctx.stats().total_ms
     for p in (p_rays, p_start, p_out):
         p.close()
 
