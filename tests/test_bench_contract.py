@@ -1,6 +1,6 @@
 """The JSON line bench.py prints (driver contract): checked on the committed output of the last GPU run
-(profiles/r03a_bench.json and r03b_bench.json are what `python bench.py` printed on the MI355X box, r03b on the round's final
-tree) and on bench.py's own source."""
+(profiles/r03a_bench.json, r03b_bench.json and r03c_bench.json are what `python bench.py` printed on the MI355X box, r03c on the
+round's final tree, with the `pipelined` leg) and on bench.py's own source."""
 import json
 import os
 import re
@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["r03a_bench.json", "r03b_bench.json"])
+@pytest.mark.parametrize("name", ["r03a_bench.json", "r03b_bench.json", "r03c_bench.json"])
 def test_committed_bench_line_has_every_contract_key(name):
     j = json.load(open(os.path.join(ROOT, "profiles", name)))
     for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "backend", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -48,6 +48,18 @@ def test_committed_bench_line_has_every_contract_key(name):
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["id_mismatches_vs_gpu"] == 0 and 1 <= c["cores"] <= c["host_cpus_visible"]
     assert abs(j["value"] - j["config"]["rays_per_step_per_gpu"] * j["n_gpus"] / (j["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * j["value"]
     assert j["other_traversal"]["traversal"] == "min_t" and j["other_traversal"]["ids_differing_from_exact"] == 0
+    if name >= "r03c":
+        # the same K batches with two in flight (pt_trace_closest_dev_submit): beside the headline, never instead of it; same hits;
+        # its fractions of the two ceilings are the headline's scaled by the time per launch, and stay below 1
+        pl = j["pipelined"]
+        assert pl["unit"] == "Mrays/s" and pl["in_flight"] == 2 and pl["steps"] == j["steps"] and pl["hits_equal_blocking_call"] is True
+        assert abs(pl["value"] - j["config"]["rays_per_step_per_gpu"] / (pl["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * pl["value"]
+        assert j["value"] < pl["value"] < 1.6 * j["value"]
+        fc = pl["frac_of_ceilings"]
+        assert set(fc) == {"valu-issue", "l1-lane-loads"} and all(0.3 < v < 1.0 for v in fc.values())
+        assert abs(fc[r["bound"]] - r["frac"] * r["kernel_ms"] / pl["ms_per_step"]) < 1e-9
+        s3 = open(os.path.join(ROOT, "profiles", "r03c_summary.txt")).read()
+        assert "k_trace_scoped_persistent<12, false>" in s3 and "23 calls" in s3      # every launch in the trace is one launch alone (--in-flight 1)
     s = j["spectral"]
     assert s["unit"] == "spp/s" and s["cpu_baseline"]["pixels_differing_vs_gpu"] == 0 and s["scaling"] == "weak"
     sr = s["roofline"]

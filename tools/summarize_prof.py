@@ -59,6 +59,6 @@ if "FETCH_SIZE" in means:
     t["tris"] = int(os.environ.get("PT_PROF_TRIS", "1000000"))
     t["rays"] = int(os.environ.get("PT_PROF_RAYS", "2073600"))
     t["source"] = (f"profiles/{tag}_summary.txt (rocprofv3 --pmc passes of `bench.py --steps 20 --warmup 2 --no-cpu-baseline "
-                   f"--spectral-spp 0 --config4-spp 0`, one pass per counter group, mean over the launches of the traversal kernel)")
+                   f"--spectral-spp 0 --config4-spp 0 --in-flight 1`, one pass per counter group, mean over the launches of the traversal kernel)")
     json.dump(t, open(os.path.join(out, f"traffic_{tag}.json"), "w"), indent=1)
     print("## traffic", json.dumps(t))
