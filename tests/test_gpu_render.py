@@ -335,6 +335,28 @@ def test_a_slice_of_the_long_sweeps():
         r["scenes"], r["rays"], r["images"], {k: v for k, v in r["tie_id_mismatches"].items() if v}, {k: v for k, v in r["within_rounding_mismatches"].items() if v}))
 
 
+def test_a_sweep_slice_through_chunks_on_two_trace_slots():
+    """The same kind of sweep with pt_trace_closest cutting every 20 000-ray batch into chunks of 4 096 rays whose kernels
+    alternate between two trace slots (PTC_HOST_CHUNK; the streams and scratch of pt_trace_closest_dev_submit): launches of
+    the same scene overlap on the GPU, each with its own ticket words, stack columns and redo list, and every hit is still the
+    recursion's.  Seeds from the range the builder swept this way (30000-39999, profiles/r03c_fuzz_slots_*.json)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seeds = list(range(30000, 40000, 167))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--seed-list", ",".join(map(str, seeds))],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, PTC_HOST_CHUNK="4096", PTC_HOST_SLOTS="2"))
+    assert p.returncode in (0, 1) and p.stdout.strip().startswith("{"), p.stdout[-3000:] + p.stderr[-3000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["scenes"] + r["build_errors_agreed"] == len(seeds) and r["scenes"] >= 55
+    assert all(" mode 0: " in f for f in r["failures"]) and r["t_mismatches"] == len(r["failures"]) <= 1, r["failures"]
+    for key in ("reference-tree/exact", "reference-tree/replay", "lbvh/exact", "lbvh/replay"):
+        assert r["tie_id_mismatches"].get(key, 0) == 0, (key, r["tie_examples"])
+    assert r["pixels_differing"].get("reference-tree/exact", 0) == 0 and r["pixels_differing"].get("lbvh/exact", 0) == 0
+
+
 def test_normalised_sky_direction_extension(oracle, gpu_ctx):
     """PT_RENDER_NORMALIZE_SKY_DIRECTION: off, the Hosek-Wilkie sky sees |d| up to 2 and many pixels are NaN, as in the
     reference; on, no sample is NaN.  Either way the GPU image equals the CPU restatement's with the same flag."""
