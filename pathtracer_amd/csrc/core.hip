@@ -771,8 +771,6 @@ extern "C" int pt_host_alloc(size_t bytes, void** out) {
 }
 extern "C" void pt_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
-static int ptc_slot_setup(pt_ctx* ctx, ptc_trace_slot& sl);
-
 static int trace_closest_host(pt_ctx* ctx, const pt_scene* scene, const pt_ray* rays, const uint32_t* start_tri, uint32_t n, pt_hit* out) {
     const size_t rb = (size_t)n * sizeof(pt_ray), sb = (size_t)n * sizeof(uint32_t), hb = (size_t)n * sizeof(pt_hit);
     const size_t sb_pad = (sb + 255) & ~(size_t)255;
