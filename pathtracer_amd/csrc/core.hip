@@ -106,6 +106,7 @@ static int pt_init_body(const int* device_ids, int n, pt_ctx** out) {
     };
     ctx->tune_blocks_per_cu = std::max(1u, std::min(8u, env_u32("PTC_BLOCKS_PER_CU", ctx->tune_blocks_per_cu)));
     ctx->tune_refill = env_u32("PTC_REFILL", ctx->tune_refill);
+    ctx->tune_refill_queued = env_u32("PTC_REFILL_QUEUED", getenv("PTC_REFILL") ? ctx->tune_refill : ctx->tune_refill_queued);     // (PTC_REFILL alone sets both)
     ctx->tune_ticket = env_u32("PTC_TICKET", ctx->tune_ticket);
     ctx->tune_wide_collapse = std::min(2u, env_u32("PTC_WIDE_COLLAPSE", ctx->tune_wide_collapse));
     ctx->tune_shade_blocks_per_cu = std::max(1u, env_u32("PTC_SHADE_BLOCKS_PER_CU", ctx->tune_shade_blocks_per_cu));

@@ -142,7 +142,8 @@ struct pt_ctx {
                                          // persistent kernels, then the two redo counters (256 B apart)
     // tuning knobs (defaults chosen by measurement; PTC_* environment variables override)
     uint32_t tune_blocks_per_cu = 6;
-    uint32_t tune_refill = 16;
+    uint32_t tune_refill = 16;           // idle lanes at which a wave of a persistent traversal kernel takes new rays: caller's batches
+    uint32_t tune_refill_queued = 32;    // the same for the integrator's queued launches (neighbouring queue entries are neighbouring samples: larger groups share more lines)
     uint32_t tune_wide_collapse = 0;     // wide records of caller-supplied trees: 0 on the device, 1 on the host, 2 both + compare
     uint32_t tune_flatten = 0;           // caller-supplied node vectors are validated and flattened: 0 on the device, 1 on the host, 2 both + compare
     bool     tune_trust_joins = false;   // PTC_TRUST_JOINS=1 (tests only): skip the joins_exact fallback, to show what it prevents

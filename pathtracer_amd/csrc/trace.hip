@@ -108,7 +108,11 @@ int ptc_launch_trace_in(pt_ctx* ctx, const pt_scene* scene, const pt_ray* d_rays
     uint4* out = reinterpret_cast<uint4*>(d_out);
     dim3 grid(blocks), block(PTC_BLOCK);
     const bool q = d_queue != nullptr;
-    const uint32_t refill = ctx->tune_refill < 1u ? 1u : (ctx->tune_refill > 64u ? 64u : ctx->tune_refill);
+    // the integrator's launches (a queue of path positions: tens of millions of incoherent rays whose queue neighbours are samples of
+    // the same pixel) refill in larger groups than a caller's batch: config 3 223 -> 230 spp/s, config 4 54.7 -> 56.1, where 2 M-ray
+    // batches of bounce rays prefer 16 (tools/sweep_knobs_render.sh)
+    const uint32_t refill_want = q ? ctx->tune_refill_queued : ctx->tune_refill;
+    const uint32_t refill = refill_want < 1u ? 1u : (refill_want > 64u ? 64u : refill_want);
     const uint32_t tsize = ctx->tune_ticket < 1u ? 1u : (ctx->tune_ticket > 1024u ? 1024u : ctx->tune_ticket);
     // this launch's ticket words (sets 2 KiB apart) and the set it clears for the next launch
     auto next_tickets = [&](uint32_t*& cur_set, uint32_t*& next_set) {
