@@ -10,6 +10,9 @@
 #define PTC_POPS_PER_TRIP 1
 #endif
 #define PTC_FIRST 64u              /* rays of a wave's static first block (one per lane) */
+#ifndef PTC_LEAF_EVERY
+#define PTC_LEAF_EVERY 2           /* k_trace_scoped_persistent: the leaf test runs on every 2nd loop trip (1: every trip), see there */
+#endif
 // -DPTC_MARKERS (analysis builds only, tools/issue_mix.py): comment lines in the assembly at the start of the hot blocks of
 // k_trace_scoped_persistent, so that the VALU opcode mix of each block can be read off `hipcc -S`
 // (tests/cpp/emu_trace.cpp compiles this header for the CPU, where the occupancy attribute does not exist)
@@ -330,6 +333,9 @@ __global__ __launch_bounds__(PTC_BLOCK) PTC_WAVES_PER_EU(4, 5) void k_trace_scop
     uint32_t ray_i = 0u, skip = PT_NO_TRIANGLE, cur = PTC_IDLE, best_id = PT_NO_TRIANGLE;
     float best_t = pt_inf(), best_u = 0.0f, best_v = 0.0f;
     float m_cur = pt_inf();          // minimum t found since the newest stack entry was pushed (inf: none)
+#if PTC_LEAF_EVERY > 1
+    uint32_t leaf_trip = 0u;         // loop trips of this wave (wave-uniform): the leaf test runs on every PTC_LEAF_EVERY-th
+#endif
     bool sign_ok = true;             // this lane's ray allows the sign-select wide step (an idle lane does not object)
     uint32_t near_x = 0u, near_y = 16u, near_z = 32u;      // byte offsets of its near planes inside a wide record
 
@@ -415,7 +421,20 @@ __global__ __launch_bounds__(PTC_BLOCK) PTC_WAVES_PER_EU(4, 5) void k_trace_scop
             }
         }
         // ---- phase 2: leaf (bvh.rs:327-336) ----
-        {
+        // The leaf test is executed by the wave whenever a lane needs it - with ~12 of 64 lanes on nearly every trip, a third of the
+        // kernel's VALU instructions.  So it runs on every SECOND trip only (PTC_LEAF_EVERY), or at once when no lane of the wave is
+        // at a record: a lane that reaches a leaf on an odd trip keeps its leaf for one trip, and the test then serves about twice
+        // the lanes.  The wait is bounded by one trip, which is what separates this from the forms that lost (lanes waiting until 8 - 24
+        // of them are there; every third trip: equal): primaries 0.997 -> 0.973 ms, bounce rays 1.173 -> 1.149, config 3 230.4 -> 236.5
+        // spp/s, same bits (a lane's own sequence of visits does not change).  Also tried on top, all equal to the plain form:
+        // every trip once the tickets are gone, and at once when 16 or 24 lanes wait.
+#if PTC_LEAF_EVERY > 1
+        leaf_trip += 1u;
+        const bool leaf_now = (leaf_trip % PTC_LEAF_EVERY) == 0u || __ballot(has_ray && !(cur & PTC_LEAF_BIT)) == 0ull;
+#else
+        const bool leaf_now = true;
+#endif
+        if (leaf_now) {
             if (has_ray && (cur & PTC_LEAF_BIT) && cur != PTC_IDLE) {
                 const uint32_t tri = cur & PTC_INDEX_MASK;
                 if (tri != skip) {

@@ -1,7 +1,7 @@
 """The JSON line bench.py prints (driver contract): checked on the committed output of the last GPU run
-(profiles/r03d_bench.json is what `python bench.py` printed on the MI355X box on the round's final tree; the counter files it is
-checked against - profiles/traffic.json, integrator_traffic.json, r03d_summary.txt - are the PMC passes of that same tree; the
-earlier r03a / r03b / r03c lines stay under profiles/ as records of their own trees) and on bench.py's own source."""
+(profiles/r03e_bench.json is what `python bench.py` printed on the MI355X box on the round's final tree; the counter files it is
+checked against - profiles/traffic.json, integrator_traffic.json, r03e_summary.txt - are the PMC passes of that same tree; the
+earlier r03a - r03d lines stay under profiles/ as records of their own trees) and on bench.py's own source."""
 import json
 import os
 import re
@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["r03d_bench.json"])
+@pytest.mark.parametrize("name", ["r03e_bench.json"])
 def test_committed_bench_line_has_every_contract_key(name):
     j = json.load(open(os.path.join(ROOT, "profiles", name)))
     for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "backend", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -41,7 +41,7 @@ def test_committed_bench_line_has_every_contract_key(name):
     assert abs(vi["valu_busy"] - t["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * t["GRBM_GUI_ACTIVE"] / 8)) < 1e-9 and 0.4 < vi["valu_busy"] < 0.9
     ij = json.load(open(os.path.join(ROOT, "profiles", "issue_roof.json")))
     assert vi["peak"] == ij["wave_instr_per_s_kernel_mix"] and "tools/issue_mix.py" in ij["source"] and set(ij["hot_block_mix"]) >= {"record_sign", "leaf", "pop"}
-    summary = open(os.path.join(ROOT, "profiles", "r03d_summary.txt")).read()
+    summary = open(os.path.join(ROOT, "profiles", "r03e_summary.txt")).read()
     assert "k_trace_scoped_persistent" in summary and "SQ_INSTS_VALU" in summary and "TCP_TOTAL_CACHE_ACCESSES_sum" in summary
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "host_cpus_visible"):
@@ -59,7 +59,7 @@ def test_committed_bench_line_has_every_contract_key(name):
         fc = pl["frac_of_ceilings"]
         assert set(fc) == {"valu-issue", "l1-lane-loads"} and all(0.3 < v < 1.0 for v in fc.values())
         assert abs(fc[r["bound"]] - r["frac"] * r["kernel_ms"] / pl["ms_per_step"]) < 1e-9
-        s3 = open(os.path.join(ROOT, "profiles", "r03d_summary.txt")).read()
+        s3 = open(os.path.join(ROOT, "profiles", "r03e_summary.txt")).read()
         assert "k_trace_scoped_persistent<12, false>" in s3 and "23 calls" in s3      # every launch in the trace is one launch alone (--in-flight 1)
     s = j["spectral"]
     assert s["unit"] == "spp/s" and s["cpu_baseline"]["pixels_differing_vs_gpu"] == 0 and s["scaling"] == "weak"
