@@ -21,7 +21,8 @@
 //         iff t <= best, in the recursion's visiting order) and, for every pending far sibling, the minimum t found since
 //         it was pushed: the "scope minimum".  Scopes nest like the stack, so ONE register holds the innermost scope's
 //         minimum (m_cur): a push starts a new scope (m_cur = inf, after parking a finite m_cur in a RESTORE entry), a
-//         pop closes one (the decision `m_cur > entry`, then the parked value folds back in: min).  The per-record
+//         pop closes one (the decision `m_cur > entry`, then the parked value folds back in: min).  Per loop trip a lane may
+//         visit a record, test a leaf (that phase runs on every second trip of the wave, trace_kernels.h) and pop once.  The per-record
 //         decisions are ptc_wide_step (trace_step.h), shared with the host-side model that the CPU tests check against
 //         the oracle.  A ray with a non-finite component, or one that meets a triangle at a non-finite distance (where
 //         Some(inf) / Some(NaN) and None part ways in bvh.rs:280-303), is handed to REPLAY through a redo list.
